@@ -1,0 +1,194 @@
+// K7 — encoder self-attention, flash style: softmax(Q K^T / 8) V, non-causal,
+// T = 1500 keys, head dim 64.  One workgroup = (batch b, head h, 128 queries);
+// each of the 4 waves owns 32 queries.
+//
+// gfx950 mapping
+//  * S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K tile rows from LDS, B = the wave's
+//    Q fragment held in registers): the accumulator puts ONE query per lane (column
+//    j = lane&31) and 16 keys per 32-key block in its registers, so the row max / sum
+//    need a single cross-lane exchange (lane ^ 32) instead of a shuffle tree.
+//  * O^T = V^T P^T: the contraction index of an MFMA may be any permutation as long as
+//    both operands agree, so the P fragment is just the lane's own 8 accumulator values
+//    (keys {0..3, 8..11} + 4*(lane>>5) + 16*ks) and the V^T fragment reads the same keys
+//    from a time-contiguous V^T tile — no P shuffle, no LDS round trip for P.
+//  * V is consumed transposed ([dh][time]); the QKV GEMM's TRANS epilogue emits it
+//    in that layout, so no transpose pass exists anywhere.
+//  * K tile: 128-byte rows, XOR-swizzled 16-byte chunks (conflict-free ds_read_b128);
+//    V^T tile: rows padded to 136 bytes (conflict-free ds_read_b64).
+//  * register-staged double buffering: next tile's global loads are issued before
+//    the MFMA/softmax block, written to LDS after it; one barrier per 64-key tile.
+//  * online softmax in fp32 with exp2 (scores pre-multiplied by log2 e).
+#include "common.h"
+#include "kernels.h"
+
+#define AE_Q 128
+#define AE_KV 64
+#define AE_VSTRIDE 68 /* halves per V^T tile row (136 B) */
+
+__global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
+                                                       int64_t ld, int64_t qk_bstride,
+                                                       const half_t* __restrict__ vt, int64_t ldvt,
+                                                       int64_t vt_bstride, half_t* __restrict__ out, int64_t ldo,
+                                                       int64_t o_bstride, int T) {
+  __shared__ __attribute__((aligned(16))) half_t sK[2][AE_KV * 64];
+  __shared__ __attribute__((aligned(16))) half_t sV[2][64 * AE_VSTRIDE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AE_Q;
+
+  const half_t* qb = q + (size_t)b * qk_bstride + h * 64;
+  const half_t* kb = k + (size_t)b * qk_bstride + h * 64;
+  const half_t* vb = vt + (size_t)b * vt_bstride + (size_t)(h * 64) * ldvt;
+
+  // Q fragment (B operand): query row l31 of this wave, d = ks*16 + hi*8 .. +7, pre-scaled by 1/8
+  half8_t qf[4];
+  {
+    int qr = q0 + wave * 32 + l31;
+    if (qr > T - 1) qr = T - 1;
+    const half_t* qp = qb + (size_t)qr * ld + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8_t v = *reinterpret_cast<const half8_t*>(qp + ks * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
+      qf[ks] = v;
+    }
+  }
+
+  // staging map: rows r0, r0+32; 16-byte chunk c
+  const int c = tid & 7, r0 = tid >> 3;
+  const int nkt = (T + AE_KV - 1) / AE_KV;
+  intx4 rk[2], rv[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + 32 * i;
+      int key = kt * AE_KV + row;
+      if (key > T - 1) key = T - 1;
+      rk[i] = *reinterpret_cast<const intx4*>(kb + (size_t)key * ld + c * 8);
+      rv[i] = *reinterpret_cast<const intx4*>(vb + (size_t)row * ldvt + kt * AE_KV + c * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + 32 * i;
+      *reinterpret_cast<intx4*>(&sK[buf][row * 64 + ((c ^ ((row >> 1) & 7)) << 3)]) = rk[i];
+      intx2* dv = reinterpret_cast<intx2*>(&sV[buf][row * AE_VSTRIDE + c * 8]);
+      dv[0] = intx2{rv[i][0], rv[i][1]};
+      dv[1] = intx2{rv[i][2], rv[i][3]};
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  floatx16 o[2] = {floatx16{0}, floatx16{0}};
+  float m_run = -1.0e30f, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < nkt;
+    if (more) gload(kt + 1);
+
+    // ---- S^T[key][query] for the 64 keys of this tile ----
+    floatx16 s[2] = {floatx16{0}, floatx16{0}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = ks * 2 + hi;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        const int row = kb2 * 32 + l31;
+        const half8_t kf = *reinterpret_cast<const half8_t*>(&sK[cur][row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3)]);
+        s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb2], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (one query per lane; partner lane^32 holds the other keys) ----
+    const int kbase = kt * AE_KV + 4 * hi;
+    const bool tail = (kt * AE_KV + AE_KV) > T;
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[kb2][r] * LOG2E;
+        if (tail) {
+          const int key = kbase + kb2 * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= T) v = -1.0e30f;
+        }
+        s[kb2][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[kb2][r] - m_new);
+        s[kb2][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T[dh][query] += V^T[dh][key] * P^T[key][query] ----
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        half8_t pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (half_t)s[kb2][ks2 * 8 + e];
+        const int koff = kb2 * 32 + ks2 * 16 + 4 * hi;  // keys koff+{0..3}, koff+8+{0..3}
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const half_t* vr = &sV[cur][(dt * 32 + l31) * AE_VSTRIDE + koff];
+          const half4_t v0 = *reinterpret_cast<const half4_t*>(vr);
+          const half4_t v1 = *reinterpret_cast<const half4_t*>(vr + 8);
+          half8_t vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+        }
+      }
+
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane = query, 4 consecutive dh per register group ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qr = q0 + wave * 32 + l31;
+  if (qr < T) {
+    half_t* op = out + (size_t)b * o_bstride + (size_t)qr * ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4_t ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (half_t)(o[dt][g * 4 + e] * inv);
+        *reinterpret_cast<half4_t*>(op + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+  }
+}
+
+namespace fwk {
+void launch_attn_enc(hipStream_t st, const half_t* q, const half_t* k, int64_t ld, int64_t qk_bstride,
+                     const half_t* vt, int64_t ldvt, int64_t vt_bstride, half_t* out, int64_t ldo,
+                     int64_t o_bstride, int B, int H, int T) {
+  dim3 grid((T + AE_Q - 1) / AE_Q, H, B);
+  attn_enc_kernel<<<grid, 256, 0, st>>>(q, k, ld, qk_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, T);
+}
+}  // namespace fwk

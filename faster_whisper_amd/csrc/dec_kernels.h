@@ -1,0 +1,43 @@
+// Launch API of the decoder-step kernels (dec_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace fwd {
+
+constexpr int FIN_CAP = 48;  // finished hypotheses kept per chunk (>= round(K*patience) + K)
+
+// Per-generate constants handed to the kernels by value.
+struct GenDev {
+  int B, K, R;             // chunks, beams per chunk, rows = B*K
+  int P;                   // prompt length (all prompts of a call have the same length)
+  int budget;              // max new tokens
+  int max_fin;             // round(K * patience)
+  int V, n_text_ctx;
+  int with_ts, suppress_blank, min_new, mits, ngram;
+  float rep_pen, lp_pow;
+  int eot, no_ts, ts_begin;
+  int n_sup_begin, sup_begin[8];
+};
+
+void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, int rows, int d,
+                  const int* d_step, int pos_fixed, int P);
+int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const half_t* res,
+                    int ldr, void* out, int ldo, int R, int N, int K, int act, bool out_f32);
+void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
+                      const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
+                      int pos_fixed, int P, int R_total);
+void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
+                       int kmul, half_t* out, int B, int H, const int* done);
+void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
+void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
+                           const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok);
+void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val, const int* cand_tok, int* hist2,
+                        float* cum2, uint8_t* kvidx2, int* cur_tok, const int* d_step, int* done, int* n_done,
+                        int* n_fin, int* fin_tok, int* fin_len, float* fin_score, float* fin_cum);
+void launch_step_advance(hipStream_t st, int* d_step);
+void launch_token_prob(hipStream_t st, const float* logits, int V, const int* target, float* out, int out_stride,
+                       int out_off, int rows);
+void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, const int* heads,
+                        int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B);
+
+}  // namespace fwd

@@ -1,0 +1,772 @@
+// K12-K20, K22-K23 — decoder-step kernels for gfx950.
+//
+// One decode step works on R = B*K rows (B chunks x K beams).  Everything a step needs
+// (step counter, beam parents, token history, KV-slot indirection) lives in HBM, so the
+// whole step is a fixed launch sequence that is captured once in a hipGraph and replayed;
+// the host only polls a "chunks done" counter every few steps.
+//
+// The step is HBM-bound: weights are streamed once per step by the
+// skinny MFMA GEMM below, the cross-attention K/V of a chunk is streamed once per step and
+// SHARED by the K beams of that chunk (they are the 16 columns of one MFMA tile), and the
+// self-attention cache is never copied on a beam reorder — rows read their ancestors'
+// slots through a [row][position] -> slot table instead.
+#include "common.h"
+#include "dec_kernels.h"
+
+// ------------------------------------------------------------------------------------
+// K12: token + learned-position embedding  x[r] = E[tok[r]] + pos[p]
+// ------------------------------------------------------------------------------------
+__global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __restrict__ emb,
+                                 const half_t* __restrict__ pos_emb, half_t* __restrict__ x, int d,
+                                 const int* __restrict__ d_step, int pos_fixed, int P) {
+  const int r = blockIdx.x;
+  const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + *d_step;
+  const half2_t* e = reinterpret_cast<const half2_t*>(emb + (size_t)tok[r] * d);
+  const half2_t* pe = reinterpret_cast<const half2_t*>(pos_emb + (size_t)pos * d);
+  half2_t* xo = reinterpret_cast<half2_t*>(x + (size_t)r * d);
+  for (int i = threadIdx.x; i < d / 2; i += blockDim.x) {
+    const half2_t a = e[i], b = pe[i];
+    half2_t o;
+    o[0] = (half_t)((float)a[0] + (float)b[0]);
+    o[1] = (half_t)((float)a[1] + (float)b[1]);
+    xo[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K13/K15/K16: skinny GEMM  out[r][n] = epi( sum_k x[r][k] W[n][k] ),  r < R <= 16*MT
+// Weight-streaming kernel: one workgroup owns 16 output columns; its 4 waves split K and
+// reduce through LDS in a fixed order (deterministic).  v_mfma_f32_16x16x32_f16 with
+// A = W rows (n), B = x rows, so a lane ends with 4 consecutive n of one row.
+// ------------------------------------------------------------------------------------
+template <int MT, bool OUT_F32>
+__global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict__ x, int ldx,
+                                                       const half_t* __restrict__ W,
+                                                       const half_t* __restrict__ bias,
+                                                       const half_t* __restrict__ res, int ldr, void* __restrict__ outv,
+                                                       int ldo, int R, int N, int K, int act) {
+  __shared__ float red[4][MT][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kq = K >> 2;  // per-wave K range
+  const int kbase = wave * kq + g * 8;
+  int wrow = n0 + i; if (wrow > N - 1) wrow = N - 1;
+  const half_t* wp = W + (size_t)wrow * K + kbase;
+  const half_t* xp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int xr = mt * 16 + i; if (xr > R - 1) xr = R - 1;
+    xp[mt] = x + (size_t)xr * ldx + kbase;
+  }
+  floatx4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0, 0, 0, 0};
+  const int steps = kq >> 5;
+#pragma unroll 4
+  for (int ks = 0; ks < steps; ++ks) {
+    const half8_t wf = *reinterpret_cast<const half8_t*>(wp + ks * 32);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const half8_t xf = *reinterpret_cast<const half8_t*>(xp[mt] + ks * 32);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][mt][lane][e] = acc[mt][e];
+  __syncthreads();
+  for (int mt = wave; mt < MT; mt += 4) {
+    const int row = mt * 16 + i;
+    if (row >= R) continue;
+    const int n = n0 + 4 * g;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = ((red[0][mt][lane][e] + red[1][mt][lane][e]) + red[2][mt][lane][e]) + red[3][mt][lane][e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e >= N) continue;
+      float t = v[e];
+      if (bias) t += (float)bias[n + e];
+      if (act == 1) t = gelu_erf(t);
+      if (res) t += (float)res[(size_t)row * ldr + n + e];
+      if (OUT_F32)
+        reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = t;
+      else
+        reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K13: decoder self-attention for one (row, head), KV cache with slot indirection.
+// cache layout [slot][H][n_ctx][64].  The new K/V (position pos) are written to the row's
+// own slot; older positions are read from kvidx[row][p] (slot inside the chunk).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
+                                                           half_t* __restrict__ vc, int n_ctx, int H,
+                                                           const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
+                                                           half_t* __restrict__ out, const int* __restrict__ d_step,
+                                                           int pos_fixed, int P, int R_total) {
+  __shared__ float sq[64];
+  __shared__ float sp[448];
+  __shared__ int ssrc[448];
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x, r = blockIdx.y;
+  const int step = *d_step;
+  const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + step;
+  const int c = r / kmul, kb = r - c * kmul;
+  const int slot = c * Kbeam + kb;
+  const int cur = (pos_fixed >= 0) ? 0 : (step & 1);
+  const uint8_t* kvidx = kvidx2 + ((size_t)cur * R_total + slot) * n_ctx;
+  const half_t* qr = qkv + (size_t)r * 3 * d + h * 64;
+  const float q = (float)qr[lane] * 0.125f;
+  const half_t knew = qr[d + lane], vnew = qr[2 * d + lane];
+  const size_t head_stride = (size_t)n_ctx * 64;
+  const size_t slot_stride = (size_t)H * head_stride;
+  kc[slot * slot_stride + h * head_stride + (size_t)pos * 64 + lane] = knew;
+  vc[slot * slot_stride + h * head_stride + (size_t)pos * 64 + lane] = vnew;
+  sq[lane] = q;
+  __syncthreads();
+  const float s_new = wave_sum(q * (float)knew);
+  float mx = s_new;
+  for (int p = lane; p < pos; p += 64) {
+    const int src = c * Kbeam + kvidx[p];
+    ssrc[p] = src;
+    const half8_t* kr = reinterpret_cast<const half8_t*>(kc + src * slot_stride + h * head_stride + (size_t)p * 64);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const half8_t kv = kr[j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += sq[j * 8 + e] * (float)kv[e];
+    }
+    sp[p] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int p = lane; p < pos; p += 64) {
+    const float e = __expf(sp[p] - mx);
+    sp[p] = e;
+    sum += e;
+  }
+  const float e_new = __expf(s_new - mx);
+  sum = wave_sum(sum) + e_new;
+  __syncthreads();
+  float acc = 0.f;
+  const half_t* vb = vc + h * head_stride + lane;
+  int p = 0;
+  for (; p + 4 <= pos; p += 4) {
+    const float v0 = (float)vb[ssrc[p] * slot_stride + (size_t)p * 64];
+    const float v1 = (float)vb[ssrc[p + 1] * slot_stride + (size_t)(p + 1) * 64];
+    const float v2 = (float)vb[ssrc[p + 2] * slot_stride + (size_t)(p + 2) * 64];
+    const float v3 = (float)vb[ssrc[p + 3] * slot_stride + (size_t)(p + 3) * 64];
+    acc += sp[p] * v0 + sp[p + 1] * v1 + sp[p + 2] * v2 + sp[p + 3] * v3;
+  }
+  for (; p < pos; ++p) acc += sp[p] * (float)vb[ssrc[p] * slot_stride + (size_t)p * 64];
+  acc += e_new * (float)vnew;
+  out[(size_t)r * d + h * 64 + lane] = (half_t)(acc / sum);
+}
+
+// ------------------------------------------------------------------------------------
+// K14: decoder cross-attention.  One workgroup = (chunk, head); the kmul (<= 16) beam
+// queries of the chunk are the 16 columns of the MFMA tiles, so the chunk's K / V^T
+// (the dominant HBM stream of the whole decode: 2*1500*64*2 B per (chunk, head, layer))
+// is read ONCE for all beams, straight from HBM into MFMA operands (no LDS staging:
+// every byte is used exactly once per workgroup).
+//   S^T tile = K rows x Q^T     (A row i of sub-tile t holds key base+8*(i>>2)+4t+(i&3), so a
+//                                lane ends with 8 CONSECUTIVE keys of its query)
+//   O^T tile = V^T x P^T        (A = 16 bytes of a time-contiguous V^T row)
+// 4 waves stride over 32-key groups with an online softmax each; merged through LDS.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
+                                                             const half_t* __restrict__ ck,
+                                                             const half_t* __restrict__ cvt, int T, int t_pad,
+                                                             int kmul, half_t* __restrict__ out,
+                                                             const int* __restrict__ done) {
+  __shared__ float sm[4][16], sl[4][16];
+  __shared__ float so[4][16][65];
+  const int h = blockIdx.x, c = blockIdx.y;
+  if (done && done[c]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const half_t* kbase = ck + (size_t)c * T * d + h * 64;
+  const half_t* vbase = cvt + ((size_t)c * d + h * 64) * t_pad;
+  half8_t qf[2];
+  {
+    if (j < kmul) {
+      const half_t* qp = qx + (size_t)(c * kmul + j) * d + h * 64 + g * 8;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8_t v = *reinterpret_cast<const half8_t*>(qp + s * 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
+        qf[s] = v;
+      }
+    } else {
+      qf[0] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      qf[1] = qf[0];
+    }
+  }
+  floatx4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = floatx4{0, 0, 0, 0};
+  float m_run = -1.0e30f, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+  const int ngroups = (T + 31) >> 5;
+  for (int gi = wave; gi < ngroups; gi += 4) {
+    const int base = gi * 32;
+    floatx4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    {
+      // A rows: key(i, t) = base + 8*(i>>2) + 4*t + (i&3), i = lane&15
+      int k0 = base + 8 * (j >> 2) + (j & 3);
+      int k1 = k0 + 4;
+      if (k0 > T - 1) k0 = T - 1;
+      if (k1 > T - 1) k1 = T - 1;
+      const half_t* p0 = kbase + (size_t)k0 * d + g * 8;
+      const half_t* p1 = kbase + (size_t)k1 * d + g * 8;
+      const half8_t a00 = *reinterpret_cast<const half8_t*>(p0);
+      const half8_t a01 = *reinterpret_cast<const half8_t*>(p0 + 32);
+      const half8_t a10 = *reinterpret_cast<const half8_t*>(p1);
+      const half8_t a11 = *reinterpret_cast<const half8_t*>(p1 + 32);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a00, qf[0], s0, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, qf[1], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, qf[0], s1, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, qf[1], s1, 0, 0, 0);
+    }
+    // lane (query j, g) now holds keys base + 8g + {0..3} (s0) and + {4..7} (s1)
+    float sc[8];
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (e < 4 ? s0[e] : s1[e - 4]) * LOG2E;
+      if (base + 8 * g + e >= T) v = -1.0e30f;
+      sc[e] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    half8_t pf;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(sc[e] - m_new);
+      psum += pv;
+      pf[e] = (half_t)pv;
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+      const half8_t vf = *reinterpret_cast<const half8_t*>(vbase + (size_t)(dt * 16 + j) * t_pad + base + 8 * g);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+    }
+  }
+  // combine the 4 key-group lanes of a query, then the 4 waves
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (g == 0) { sm[wave][j] = m_run; sl[wave][j] = l_run; }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) so[wave][j][dt * 16 + 4 * g + e] = o[dt][e];
+  __syncthreads();
+  for (int idx = tid; idx < kmul * 64; idx += 256) {
+    const int qq = idx >> 6, dh = idx & 63;
+    float M = fmaxf(fmaxf(sm[0][qq], sm[1][qq]), fmaxf(sm[2][qq], sm[3][qq]));
+    float Lsum = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __builtin_amdgcn_exp2f(sm[w][qq] - M);
+      Lsum += sl[w][qq] * f;
+      O += so[w][qq][dh] * f;
+    }
+    out[(size_t)(c * kmul + qq) * d + h * 64 + dh] = (half_t)(O / Lsum);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K22: no-speech probability = softmax(logits at the <sot> position)[no_speech]
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dec_nospeech_kernel(const float* __restrict__ logits, int V, int row_mul,
+                                                            int no_speech_id, float* __restrict__ out) {
+  __shared__ float red[32];
+  const int b = blockIdx.x;
+  const float* lg = logits + (size_t)b * row_mul * V;
+  float mx = -3.0e38f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, lg[v]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  float m2 = -3.0e38f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m2 = fmaxf(m2, red[i]);
+  __syncthreads();
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(lg[v] - m2);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+    out[b] = __expf(lg[no_speech_id] - m2) / tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K17/K18 (+ the row part of K19): logits rules, fp32 log-softmax and the row's top-C
+// candidates of cum + logp, one workgroup per row.
+// Rule order: repetition penalty, no-repeat-ngram, suppress-blank (first
+// step), suppress list, [min_new_tokens], timestamp rules (a)-(e), log-softmax.
+// ------------------------------------------------------------------------------------
+#define LP_THREADS 1024
+struct PairMS { float m, s; };
+static __device__ __forceinline__ PairMS pair_add(PairMS a, float x) {
+  if (x == -INFINITY) return a;
+  if (x > a.m) { a.s = a.s * __expf(a.m - x) + 1.f; a.m = x; }
+  else a.s += __expf(x - a.m);
+  return a;
+}
+static __device__ __forceinline__ PairMS pair_merge(PairMS a, PairMS b) {
+  if (b.m == -INFINITY) return a;
+  if (a.m == -INFINITY) return b;
+  if (a.m >= b.m) { a.s += b.s * __expf(b.m - a.m); return a; }
+  b.s += a.s * __expf(a.m - b.m);
+  return b;
+}
+static __device__ __forceinline__ PairMS pair_wave(PairMS a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    PairMS b;
+    b.m = __shfl_xor(a.m, o, 64);
+    b.s = __shfl_xor(a.s, o, 64);
+    a = pair_merge(a, b);
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::GenDev gp, float* __restrict__ logits,
+                                                                        const uint8_t* __restrict__ sup_mask,
+                                                                        const int* __restrict__ hist2,
+                                                                        const float* __restrict__ cum2,
+                                                                        const int* __restrict__ d_step,
+                                                                        const int* __restrict__ done,
+                                                                        float* __restrict__ cand_val,
+                                                                        int* __restrict__ cand_tok) {
+  __shared__ PairMS red_t[LP_THREADS / 64], red_s[LP_THREADS / 64];
+  __shared__ float red_mt[LP_THREADS / 64];
+  __shared__ float sh_lse, sh_mask_text;
+  __shared__ float bv[LP_THREADS / 64];
+  __shared__ int bi[LP_THREADS / 64];
+  __shared__ float win_v;
+  __shared__ int win_i;
+  const int r = blockIdx.x;
+  const int c = r / gp.K;
+  if (done[c]) return;
+  const int tid = threadIdx.x;
+  const int step = *d_step;
+  const int cur = step & 1;
+  const int n = step;  // tokens generated so far on this row
+  const int* hist = hist2 + ((size_t)cur * gp.R + r) * gp.n_text_ctx;
+  float* lg = logits + (size_t)r * gp.V;
+  const int V = gp.V, tb = gp.ts_begin;
+  const float NEG = -INFINITY;
+
+  // ---- sparse rules that touch a few ids (done by single threads, then a barrier) ----
+  if (gp.rep_pen != 1.0f && n > 0) {
+    for (int i = tid; i < n; i += LP_THREADS) {
+      const int t = hist[i];
+      bool first = true;
+      for (int q = 0; q < i; ++q)
+        if (hist[q] == t) { first = false; break; }
+      if (first) {
+        const float v = lg[t];
+        lg[t] = v < 0.f ? v * gp.rep_pen : v / gp.rep_pen;
+      }
+    }
+    __syncthreads();
+  }
+  if (gp.ngram > 0 && n + 1 >= gp.ngram) {
+    const int k = gp.ngram;
+    for (int s = tid; s + k <= n; s += LP_THREADS) {
+      bool match = true;
+      for (int q = 0; q < k - 1; ++q)
+        if (hist[s + q] != hist[n - (k - 1) + q]) { match = false; break; }
+      if (match) lg[hist[s + k - 1]] = NEG;
+    }
+    __syncthreads();
+  }
+  // ---- timestamp-rule scalars ----
+  bool last_ts = false, penult_ts = true;
+  int ts_bound = tb;  // timestamps in [tb, ts_bound) are forbidden
+  if (gp.with_ts) {
+    last_ts = n >= 1 && hist[n - 1] >= tb;
+    penult_ts = n < 2 || hist[n - 2] >= tb;
+    int last_seen = -1;
+    for (int i = n - 1; i >= 0; --i)
+      if (hist[i] >= tb) { last_seen = hist[i]; break; }
+    if (last_seen >= 0) ts_bound = (last_ts && !penult_ts) ? last_seen : last_seen + 1;
+  }
+  // ---- pass 1: element-wise masks + (max, sumexp) over text ids and over timestamp ids ----
+  PairMS pt = {NEG, 0.f}, ps = {NEG, 0.f};
+  for (int v = tid; v < V; v += LP_THREADS) {
+    float x = lg[v];
+    bool kill = sup_mask[v] != 0;
+    if (n == 0 && gp.suppress_blank) {
+      for (int q = 0; q < gp.n_sup_begin; ++q) kill |= (v == gp.sup_begin[q]);
+    }
+    if (n < gp.min_new && v == gp.eot) kill = true;
+    if (gp.with_ts) {
+      if (v == gp.no_ts) kill = true;
+      if (last_ts) {
+        if (penult_ts) { if (v >= tb) kill = true; }
+        else { if (v < gp.eot) kill = true; }
+      }
+      if (v >= tb && v < ts_bound) kill = true;
+      if (n == 0) {
+        if (v < tb) kill = true;
+        if (gp.mits >= 0 && v > tb + gp.mits) kill = true;
+      }
+    }
+    if (kill) x = NEG;
+    lg[v] = x;
+    if (v < tb) pt = pair_add(pt, x); else ps = pair_add(ps, x);
+  }
+  pt = pair_wave(pt);
+  ps = pair_wave(ps);
+  if ((tid & 63) == 0) { red_t[tid >> 6] = pt; red_s[tid >> 6] = ps; }
+  __syncthreads();
+  if (tid == 0) {
+    PairMS a = red_t[0], b = red_s[0];
+    for (int i = 1; i < LP_THREADS / 64; ++i) { a = pair_merge(a, red_t[i]); b = pair_merge(b, red_s[i]); }
+    const float lse_t = a.m == NEG ? NEG : a.m + __logf(a.s);
+    const float lse_s = b.m == NEG ? NEG : b.m + __logf(b.s);
+    const PairMS all = pair_merge(a, b);
+    float lse = all.m == NEG ? NEG : all.m + __logf(all.s);
+    float mask_text = 0.f;
+    // rule (e): if logsumexp(timestamps) > max(text) (in log-prob space; the common lse cancels)
+    if (gp.with_ts && lse_s > a.m) { mask_text = 1.f; lse = lse_s; }
+    (void)lse_t;
+    sh_lse = lse;
+    sh_mask_text = mask_text;
+  }
+  __syncthreads();
+  const float lse = sh_lse;
+  const bool mask_text = sh_mask_text != 0.f;
+  // ---- pass 2: log-probs in place, per-thread best candidate ----
+  const float cum = cum2[(size_t)cur * gp.R + r];
+  float best_v = NEG;
+  int best_i = 0x7fffffff;
+  for (int v = tid; v < V; v += LP_THREADS) {
+    float x = lg[v];
+    if (mask_text && v < tb) x = NEG;
+    x = (x == NEG) ? NEG : x - lse;
+    lg[v] = x;
+    if (x > best_v) { best_v = x; best_i = v; }  // ascending v: ties keep the lowest index
+  }
+  // ---- top-C selection: C rounds of block arg-max; only the winner's owner rescans ----
+  const int C = 2 * gp.K;
+  float lim_v = INFINITY;
+  int lim_i = -1;  // last taken (value, index): candidates must come strictly after it
+  for (int cidx = 0; cidx < C; ++cidx) {
+    float v = best_v;
+    int i = best_i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(i, o, 64);
+      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = v; bi[tid >> 6] = i; }
+    __syncthreads();
+    if (tid == 0) {
+      float wv = bv[0];
+      int wi = bi[0];
+      for (int q = 1; q < LP_THREADS / 64; ++q)
+        if (bv[q] > wv || (bv[q] == wv && bi[q] < wi)) { wv = bv[q]; wi = bi[q]; }
+      win_v = wv;
+      win_i = wi;
+      cand_val[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? NEG : cum + wv;
+      cand_tok[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? 0 : wi;
+    }
+    __syncthreads();
+    lim_v = win_v;
+    lim_i = win_i;
+    if (best_i == lim_i && lim_i != 0x7fffffff) {
+      // this thread owned the winner: find its next best element after (lim_v, lim_i)
+      best_v = NEG;
+      best_i = 0x7fffffff;
+      for (int vv = tid; vv < V; vv += LP_THREADS) {
+        const float x = lg[vv];
+        const bool after = (x < lim_v) || (x == lim_v && vv > lim_i);
+        if (after && x > best_v && x != NEG) { best_v = x; best_i = vv; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K19/K20: per-chunk beam update [CT2-ext: BeamSearch::search].  Merges the K rows' top-2K
+// candidates (stable: value desc, flat index asc), walks the first K slots (EOS / last step ->
+// finished hypothesis, replaced by the next non-EOS secondary candidate), then rewrites
+// the per-row state (token history, KV-slot table, cum, next input token).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dec_beam_update_kernel(fwd::GenDev gp, const float* __restrict__ cand_val,
+                                                             const int* __restrict__ cand_tok, int* __restrict__ hist2,
+                                                             float* __restrict__ cum2, uint8_t* __restrict__ kvidx2,
+                                                             int* __restrict__ cur_tok, const int* __restrict__ d_step,
+                                                             int* __restrict__ done, int* __restrict__ n_done,
+                                                             int* __restrict__ n_fin, int* __restrict__ fin_tok,
+                                                             int* __restrict__ fin_len, float* __restrict__ fin_score,
+                                                             float* __restrict__ fin_cum) {
+  __shared__ float ov[32];
+  __shared__ int ok[32], ot[32];
+  __shared__ int s_parent[16], s_tok[16];
+  __shared__ float s_cum[16];
+  __shared__ int s_done;
+  const int c = blockIdx.x;
+  if (done[c]) return;
+  const int tid = threadIdx.x;
+  const int K = gp.K, C = 2 * K, NT = gp.n_text_ctx;
+  const int step = *d_step;
+  const int cur = step & 1, nxt = cur ^ 1;
+  const int pos = gp.P - 1 + step;
+  const bool last_step = (step + 1) >= gp.budget;
+  if (tid == 0) {
+    // ---- merge: top-C of the (live rows x C) candidates ----
+    const int nsrc = (step == 0) ? 1 : K;
+    int ptr[16];
+    for (int k = 0; k < nsrc; ++k) ptr[k] = 0;
+    int nsel = 0;
+    for (; nsel < C; ++nsel) {
+      int bk = -1;
+      float bvv = -INFINITY;
+      int btok = 0;
+      for (int k = 0; k < nsrc; ++k) {
+        if (ptr[k] >= C) continue;
+        const float v = cand_val[(size_t)(c * K + k) * 32 + ptr[k]];
+        const int t = cand_tok[(size_t)(c * K + k) * 32 + ptr[k]];
+        if (v == -INFINITY) continue;
+        if (bk < 0 || v > bvv) { bk = k; bvv = v; btok = t; }  // ascending k: ties keep lowest flat index
+      }
+      if (bk < 0) break;
+      ov[nsel] = bvv; ok[nsel] = bk; ot[nsel] = btok;
+      ptr[bk]++;
+    }
+    // ---- walk ----
+    int nf = n_fin[c];
+    int sec = K, nlive = 0;
+    for (int slot = 0; slot < K; ++slot) {
+      int jdx = slot;
+      if (jdx >= nsel) break;
+      if (ot[jdx] == gp.eot || last_step) {
+        if (nf < fwd::FIN_CAP) {
+          const int kk = ok[jdx];
+          const int* hsrc = hist2 + ((size_t)cur * gp.R + c * K + kk) * NT;
+          int* dst = fin_tok + ((size_t)c * fwd::FIN_CAP + nf) * NT;
+          int len = step;
+          for (int q = 0; q < step; ++q) dst[q] = hsrc[q];
+          if (ot[jdx] != gp.eot) { dst[len] = ot[jdx]; len++; }
+          fin_len[c * fwd::FIN_CAP + nf] = len;
+          fin_cum[c * fwd::FIN_CAP + nf] = ov[jdx];
+          const float denom = gp.lp_pow != 0.f ? powf((float)(len > 0 ? len : 1), gp.lp_pow) : 1.f;
+          fin_score[c * fwd::FIN_CAP + nf] = ov[jdx] / denom;
+          nf++;
+        }
+        if (last_step) continue;
+        while (sec < nsel && ot[sec] == gp.eot) sec++;
+        jdx = sec++;
+        if (jdx >= nsel) continue;
+      }
+      s_parent[nlive] = ok[jdx]; s_tok[nlive] = ot[jdx]; s_cum[nlive] = ov[jdx];
+      nlive++;
+    }
+    n_fin[c] = nf;
+    const bool fin = last_step || nf >= gp.max_fin || nlive == 0;
+    if (fin) {
+      done[c] = 1;
+      atomicAdd(n_done, 1);
+    } else {
+      for (int k = nlive; k < K; ++k) { s_parent[k] = s_parent[0]; s_tok[k] = s_tok[0]; s_cum[k] = -INFINITY; }
+    }
+    s_done = fin ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_done) return;
+  // ---- rewrite row state for the next step ----
+  for (int k = 0; k < K; ++k) {
+    const int pr = c * K + s_parent[k], nr = c * K + k;
+    const int* hs = hist2 + ((size_t)cur * gp.R + pr) * NT;
+    int* hd = hist2 + ((size_t)nxt * gp.R + nr) * NT;
+    const uint8_t* is = kvidx2 + ((size_t)cur * gp.R + pr) * NT;
+    uint8_t* id = kvidx2 + ((size_t)nxt * gp.R + nr) * NT;
+    for (int q = tid; q < step; q += 64) hd[q] = hs[q];
+    for (int q = tid; q < pos; q += 64) id[q] = is[q];
+    if (tid == 0) {
+      hd[step] = s_tok[k];
+      id[pos] = (uint8_t)s_parent[k];
+      cum2[(size_t)nxt * gp.R + nr] = s_cum[k];
+      cur_tok[nr] = s_tok[k];
+    }
+  }
+}
+
+__global__ void dec_step_advance_kernel(int* d_step) { *d_step += 1; }
+
+// per-token probability for align: p[r] = softmax(logits[r])[target[r]]
+__global__ __launch_bounds__(1024) void dec_token_prob_kernel(const float* __restrict__ logits, int V,
+                                                              const int* __restrict__ target, float* __restrict__ out,
+                                                              int out_stride, int out_off) {
+  __shared__ float red[32];
+  const int b = blockIdx.x;
+  const float* lg = logits + (size_t)b * V;
+  float mx = -3.0e38f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, lg[v]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  float m2 = -3.0e38f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m2 = fmaxf(m2, red[i]);
+  __syncthreads();
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(lg[v] - m2);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+    const int t = target[b];
+    out[(size_t)b * out_stride + out_off] = (t >= 0 && t < V) ? __expf(lg[t] - m2) / tot : 0.f;
+  }
+}
+
+// cross-attention probabilities of selected heads for align:
+// probs[b][hsel][tok][t] = softmax_t( q[b][head] . K[b][t][head] / 8 ),  one workgroup per (hsel, b)
+__global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __restrict__ qx, int d,
+                                                              const half_t* __restrict__ ck, int T,
+                                                              const int* __restrict__ heads, int n_sel,
+                                                              float* __restrict__ probs, int n_tok, int tok_idx) {
+  __shared__ float sq[64];
+  __shared__ float red[4];
+  const int hs = blockIdx.x, b = blockIdx.y;
+  const int h = heads[hs];
+  const int tid = threadIdx.x;
+  if (tid < 64) sq[tid] = (float)qx[(size_t)b * d + h * 64 + tid] * 0.125f;
+  __syncthreads();
+  float* pr = probs + (((size_t)b * n_sel + hs) * n_tok + tok_idx) * T;
+  float mx = -3.0e38f;
+  for (int t = tid; t < T; t += 256) {
+    const half8_t* kr = reinterpret_cast<const half8_t*>(ck + ((size_t)b * T + t) * d + h * 64);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const half8_t kv = kr[j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += sq[j * 8 + e] * (float)kv[e];
+    }
+    pr[t] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float e = __expf(pr[t] - mx);
+    pr[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int t = tid; t < T; t += 256) pr[t] *= inv;
+}
+
+namespace fwd {
+
+void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, int rows, int d,
+                  const int* d_step, int pos_fixed, int P) {
+  dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, d, d_step, pos_fixed, P);
+}
+
+template <bool F32>
+static int gemm_dispatch(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+                         const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act) {
+  const int grid = (N + 15) / 16;
+  const int mt = (R + 15) / 16;
+#define GO(MT) dec_gemm_kernel<MT, F32><<<grid, 256, 0, st>>>(x, ldx, W, bias, res, ldr, out, ldo, R, N, K, act)
+  switch (mt) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    case 5: GO(5); break;
+    case 6: GO(6); break;
+    case 7: case 8: GO(8); break;
+    default: return -1;
+  }
+#undef GO
+  return 0;
+}
+
+int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const half_t* res,
+                    int ldr, void* out, int ldo, int R, int N, int K, int act, bool out_f32) {
+  if (K % 128 != 0 || R < 1 || R > 128) return -1;
+  return out_f32 ? gemm_dispatch<true>(st, x, ldx, W, bias, res, ldr, out, ldo, R, N, K, act)
+                 : gemm_dispatch<false>(st, x, ldx, W, bias, res, ldr, out, ldo, R, N, K, act);
+}
+
+void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
+                      const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
+                      int pos_fixed, int P, int R_total) {
+  dec_self_attn_kernel<<<dim3(H, rows), 64, 0, st>>>(qkv, d, kc, vc, n_ctx, H, kvidx2, Kbeam, kmul, out, d_step,
+                                                     pos_fixed, P, R_total);
+}
+
+void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
+                       int kmul, half_t* out, int B, int H, const int* done) {
+  dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, t_pad, kmul, out, done);
+}
+
+void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {
+  dec_nospeech_kernel<<<B, 1024, 0, st>>>(logits, V, row_mul, no_speech_id, out);
+}
+
+void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
+                           const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok) {
+  dec_logits_process_kernel<<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_mask, hist2, cum2, d_step, done, cand_val,
+                                                         cand_tok);
+}
+
+void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val, const int* cand_tok, int* hist2,
+                        float* cum2, uint8_t* kvidx2, int* cur_tok, const int* d_step, int* done, int* n_done,
+                        int* n_fin, int* fin_tok, int* fin_len, float* fin_score, float* fin_cum) {
+  dec_beam_update_kernel<<<gp.B, 64, 0, st>>>(gp, cand_val, cand_tok, hist2, cum2, kvidx2, cur_tok, d_step, done,
+                                              n_done, n_fin, fin_tok, fin_len, fin_score, fin_cum);
+}
+
+void launch_step_advance(hipStream_t st, int* d_step) { dec_step_advance_kernel<<<1, 1, 0, st>>>(d_step); }
+
+void launch_token_prob(hipStream_t st, const float* logits, int V, const int* target, float* out, int out_stride,
+                       int out_off, int rows) {
+  dec_token_prob_kernel<<<rows, 1024, 0, st>>>(logits, V, target, out, out_stride, out_off);
+}
+
+void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, const int* heads,
+                        int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B) {
+  dec_cross_probs_kernel<<<dim3(n_layer_heads, B), 256, 0, st>>>(qx, d, ck, T, heads, n_sel, probs, n_tok, tok_idx);
+}
+
+}  // namespace fwd

@@ -1,0 +1,743 @@
+// Decoder side of libfwamd.so: cross-K/V projection, KV-cached decode loop with on-device
+// logits rules + beam search (hipGraph-replayed step), language detection and
+// cross-attention alignment.
+//
+// Reference interfaces replaced (faster_whisper/transcribe.py):
+//   ctranslate2.models.Whisper.generate         :222-236, :1446-1459
+//   ctranslate2.models.Whisper.detect_language  :215, :1193, :1823
+//   ctranslate2.models.Whisper.align            :1709-1715
+// The decoding rules restate CTranslate2 4.x / openai-whisper behaviour (SURVEY.md
+// Appendix A); oracle/whisper.py is the CPU statement of the same rules.
+#include "engine.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <numeric>
+
+#include "dec_kernels.h"
+#include "kernels.h"
+
+namespace fw {
+
+using fwd::FIN_CAP;
+using fwd::GenDev;
+
+struct GenWorkspace {
+  int B = 0, K = 0, R = 0, NT = 0;
+  half_t *ck = nullptr, *cvt = nullptr;  // [L][B][T][d], [L][B][d][t_pad]
+  uint64_t ckv_id = 0;                   // id of the encoder output the cross K/V belong to
+  half_t *sk = nullptr, *sv = nullptr;   // [L][R][H][NT][64]
+  half_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
+  float* logits = nullptr;               // [R][V]
+  int* prompt_dev = nullptr;             // [NT][B]
+  int* cur_tok = nullptr;                // [R]
+  int* hist2 = nullptr;                  // [2][R][NT]
+  float* cum2 = nullptr;                 // [2][R]
+  uint8_t* kvidx2 = nullptr;             // [2][R][NT]
+  float* cand_val = nullptr;             // [R][32]
+  int* cand_tok = nullptr;
+  int *done = nullptr, *n_done = nullptr, *n_fin = nullptr, *fin_tok = nullptr, *fin_len = nullptr;
+  float *fin_score = nullptr, *fin_cum = nullptr;
+  int* d_step = nullptr;
+  float* no_speech = nullptr;
+  uint8_t* sup_mask = nullptr;
+  int* zero_done = nullptr;              // [B] zeros (kernels that take a `done` pointer outside generate)
+  // graph cache for the decode step
+  hipGraphExec_t graph = nullptr;
+  GenDev graph_key;
+  bool graph_valid = false;
+  bool graphs_enabled = true;
+};
+
+static std::atomic<uint64_t> g_tensor_id{1};
+uint64_t next_tensor_id() { return g_tensor_id.fetch_add(1); }
+
+int gen_workspace_create(Model* m) {
+  const fw_config& c = m->cfg;
+  GenWorkspace* g = new GenWorkspace();
+  m->gen = g;
+  g->B = m->max_batch;
+  g->K = m->max_beam;
+  g->R = g->B * g->K;
+  g->NT = c.n_text_ctx;
+  const size_t B = g->B, R = g->R, d = c.d_model, T = c.n_audio_ctx, L = c.n_dec_layers, NT = g->NT;
+  const size_t Rg = std::max<size_t>(R, B);
+  FW_CHECK_ARG(R <= 128, "max_batch * max_beam must be <= 128 (got %zu)", R);
+  int rc;
+#define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
+  A(g->ck, L * B * T * d);
+  A(g->cvt, L * B * d * m->t_pad);
+  A(g->sk, L * R * NT * d);
+  A(g->sv, L * R * NT * d);
+  A(g->x, Rg * d); A(g->xn, Rg * d); A(g->qkv, Rg * 3 * d); A(g->att, Rg * d); A(g->qc, Rg * d);
+  A(g->ffn, Rg * 4 * d);
+  A(g->logits, Rg * c.n_vocab);
+  A(g->prompt_dev, NT * B);
+  A(g->cur_tok, Rg);
+  A(g->hist2, 2 * R * NT);
+  A(g->cum2, 2 * R);
+  A(g->kvidx2, 2 * R * NT);
+  A(g->cand_val, R * 32);
+  A(g->cand_tok, R * 32);
+  A(g->done, B); A(g->n_done, 1); A(g->n_fin, B);
+  A(g->fin_tok, B * FIN_CAP * NT); A(g->fin_len, B * FIN_CAP);
+  A(g->fin_score, B * FIN_CAP); A(g->fin_cum, B * FIN_CAP);
+  A(g->d_step, 1);
+  A(g->no_speech, B);
+  A(g->sup_mask, (size_t)c.n_vocab);
+  A(g->zero_done, B);
+#undef A
+  FW_HIP(hipMemset(g->cvt, 0, L * B * d * m->t_pad * sizeof(half_t)));
+  FW_HIP(hipMemset(g->zero_done, 0, B * sizeof(int)));
+  FW_HIP(hipMemset(g->d_step, 0, sizeof(int)));
+  const char* ng = getenv("FWAMD_NO_GRAPH");
+  g->graphs_enabled = !(ng && ng[0] == '1');
+  return FW_OK;
+}
+
+void gen_workspace_free(Model* m) {
+  GenWorkspace* g = m->gen;
+  if (!g) return;
+  if (g->graph) (void)hipGraphExecDestroy(g->graph);
+  void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->xn, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
+                  g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
+                  g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_mask,
+                  g->zero_done};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete g;
+  m->gen = nullptr;
+}
+
+// K11: cross-attention K / V^T of every decoder layer for this encoder output (once per batch)
+static int ensure_cross_kv(Model* m, const Tensor* enc) {
+  GenWorkspace* g = m->gen;
+  if (g->ckv_id == enc->id) return FW_OK;
+  const fw_config& c = m->cfg;
+  const int d = c.d_model, T = c.n_audio_ctx, B = enc->B;
+  const int64_t xs = (int64_t)T * d;
+  int rc;
+  ProfScope ps(m, PF_CROSS_KV_GEMM, 2.0 * c.n_dec_layers * B * (double)T * d * (2.0 * d), 0);
+  for (int l = 0; l < c.n_dec_layers; ++l) {
+    const DecLayerW& L = m->dec[l];
+    half_t* kd = g->ck + (size_t)l * g->B * T * d;
+    half_t* vd = g->cvt + (size_t)l * g->B * d * m->t_pad;
+    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, xs, nullptr, 0, 0, T, B, 0, false))) return rc;
+    if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
+                         true)))
+      return rc;
+  }
+  g->ckv_id = enc->id;
+  return FW_OK;
+}
+
+struct StepCfg {
+  int rows, kmul;      // rows processed, queries per chunk (1 for prefill, K for beam steps)
+  int B;
+  int pos_fixed;       // >= 0: explicit position (prefill / detect / align); -1: P-1+*d_step
+  int P;
+  const int* tok;      // [rows] device
+  bool need_logits;
+  int nospeech_rowmul; // > 0: run the no-speech kernel on rows b*rowmul after the logits GEMM
+  bool beam_tail;      // logits rules + beam update + step advance
+  const int* done;     // per-chunk done flags for cross-attn early exit
+  // align extras
+  const int* sel_heads_dev = nullptr;   // [n_sel_total] head ids, grouped per layer
+  const int* sel_layer_off = nullptr;   // host: [L+1] offsets into sel_heads
+  float* probs = nullptr; int n_sel_total = 0, n_tok = 0, tok_idx = 0;
+};
+
+#define DG(call)                                                        \
+  do {                                                                  \
+    if ((call) != 0) {                                                  \
+      set_error("decoder gemm: unsupported shape (%s)", #call);        \
+      return FW_ERUNTIME;                                               \
+    }                                                                   \
+  } while (0)
+
+static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
+  GenWorkspace* g = m->gen;
+  const fw_config& c = m->cfg;
+  const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, NT = g->NT;
+  hipStream_t st = m->stream;
+  const int rows = s.rows;
+  const double wbytes_layer = 2.0 * (12.0 * d * d);  // fp16 bytes of one layer's linears (3+1+1+1+4+4 = 14? see below)
+  (void)wbytes_layer;
+  {
+    ProfScope ps(m, PF_DEC_MISC, 0, 0);
+    fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, rows, d, g->d_step, s.pos_fixed, s.P);
+  }
+  for (int l = 0; l < c.n_dec_layers; ++l) {
+    const DecLayerW& L = m->dec[l];
+    half_t* kc = g->sk + (size_t)l * g->R * NT * d;
+    half_t* vc = g->sv + (size_t)l * g->R * NT * d;
+    const half_t* ck = g->ck + (size_t)l * g->B * T * d;
+    const half_t* cvt = g->cvt + (size_t)l * g->B * d * m->t_pad;
+    {
+      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
+      fwk::launch_layernorm(st, g->x, L.ln1.g, L.ln1.b, g->xn, rows, d);
+      DG(fwd::launch_dec_gemm(st, g->xn, d, L.qkv.w, L.qkv.b, nullptr, 0, g->qkv, 3 * d, rows, 3 * d, d, 0, false));
+    }
+    {
+      ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0);
+      fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, H, g->kvidx2, gp.K, s.kmul, g->att, rows, g->d_step,
+                            s.pos_fixed, s.P, gp.R);
+    }
+    {
+      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
+      DG(fwd::launch_dec_gemm(st, g->att, d, L.out.w, L.out.b, g->x, d, g->x, d, rows, d, d, 0, false));
+      fwk::launch_layernorm(st, g->x, L.ln2.g, L.ln2.b, g->xn, rows, d);
+      DG(fwd::launch_dec_gemm(st, g->xn, d, L.cq.w, L.cq.b, nullptr, 0, g->qc, d, rows, d, d, 0, false));
+    }
+    if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
+      ProfScope ps(m, PF_DEC_MISC, 0, 0);
+      const int off = s.sel_layer_off[l], n = s.sel_layer_off[l + 1] - off;
+      fwd::launch_cross_probs(st, g->qc, d, ck, T, s.sel_heads_dev + off, n, s.n_sel_total,
+                              s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
+      // note: probs layout [b][sel][tok][T]; the per-layer slice starts at sel offset `off`
+      (void)n;
+    }
+    {
+      ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * s.B * (double)T * d);
+      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, m->t_pad, s.kmul, g->att, s.B, H, s.done);
+    }
+    {
+      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 9.0 * d * d, 2.0 * 9.0 * d * d);
+      DG(fwd::launch_dec_gemm(st, g->att, d, L.cout.w, L.cout.b, g->x, d, g->x, d, rows, d, d, 0, false));
+      fwk::launch_layernorm(st, g->x, L.ln3.g, L.ln3.b, g->xn, rows, d);
+      DG(fwd::launch_dec_gemm(st, g->xn, d, L.ffn1.w, L.ffn1.b, nullptr, 0, g->ffn, 4 * d, rows, 4 * d, d, 1, false));
+      DG(fwd::launch_dec_gemm(st, g->ffn, 4 * d, L.ffn2.w, L.ffn2.b, g->x, d, g->x, d, rows, d, 4 * d, 0, false));
+    }
+  }
+  if (s.need_logits || s.beam_tail) {
+    ProfScope ps(m, PF_DEC_LOGITS, 2.0 * rows * (double)c.n_vocab * d, 2.0 * c.n_vocab * d);
+    fwk::launch_layernorm(st, g->x, m->dec_ln.g, m->dec_ln.b, g->xn, rows, d);
+    DG(fwd::launch_dec_gemm(st, g->xn, d, m->tok_emb, nullptr, nullptr, 0, g->logits, c.n_vocab, rows, c.n_vocab, d,
+                            0, true));
+  }
+  if (s.nospeech_rowmul > 0) {
+    ProfScope ps(m, PF_DEC_MISC, 0, 0);
+    fwd::launch_nospeech(st, g->logits, c.n_vocab, s.nospeech_rowmul, c.tok_no_speech, g->no_speech, s.B);
+  }
+  if (s.beam_tail) {
+    ProfScope ps(m, PF_DEC_SAMPLE, 0, 8.0 * rows * c.n_vocab);
+    fwd::launch_logits_process(st, gp, g->logits, g->sup_mask, g->hist2, g->cum2, g->d_step, g->done, g->cand_val,
+                               g->cand_tok);
+    fwd::launch_beam_update(st, gp, g->cand_val, g->cand_tok, g->hist2, g->cum2, g->kvidx2, g->cur_tok, g->d_step,
+                            g->done, g->n_done, g->n_fin, g->fin_tok, g->fin_len, g->fin_score, g->fin_cum);
+    fwd::launch_step_advance(st, g->d_step);
+  }
+  return FW_OK;
+}
+
+// generated-token budget: the reference treats max_length as prompt + new tokens
+// (transcribe.py:193-207). [CT2-ext] single place that decides; mirrors oracle.whisper.max_new_tokens.
+static int max_new_tokens(int max_length, int P) { return std::max(0, max_length - P); }
+
+static int check_launch(const char* what) {
+  hipError_t he = hipGetLastError();
+  if (he != hipSuccess) {
+    set_error("%s: kernel launch failed: %s", what, hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+}  // namespace fw
+
+using namespace fw;
+
+extern "C" {
+
+int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts, const int32_t* prompt_offsets,
+                    int32_t B, const fw_gen_opts* o, int32_t* out_ids, int32_t* out_lens, float* out_scores,
+                    float* out_no_speech) {
+  FW_CHECK_ARG(fm && enc_t && prompts && prompt_offsets && o && out_ids && out_lens && out_scores && out_no_speech,
+               "null argument");
+  Model* m = &fm->impl;
+  const Tensor* enc = &enc_t->impl;
+  GenWorkspace* g = m->gen;
+  const fw_config& c = m->cfg;
+  FW_CHECK_ARG(enc->owner == m, "encoder output belongs to a different model replica");
+  FW_CHECK_ARG(B == enc->B, "batch %d does not match the encoder output batch %d", B, enc->B);
+  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  const int K = o->beam_size;
+  FW_CHECK_ARG(K >= 1 && K <= m->max_beam, "beam_size %d not in [1, max_beam=%d]", K, m->max_beam);
+  FW_CHECK_ARG(o->num_hypotheses >= 1 && o->num_hypotheses <= std::max(K, 1),
+               "num_hypotheses %d must be in [1, beam_size]", o->num_hypotheses);
+  FW_CHECK_ARG(!(K == 1 && o->sampling_topk != 1),
+               "random sampling (sampling_topk != 1) belongs to the sequential fallback path, which is not built yet");
+  FW_CHECK_ARG(o->patience > 0.f, "patience must be positive");
+  FW_CHECK_ARG(o->max_length >= 1, "max_length must be positive");
+  const int P = prompt_offsets[1] - prompt_offsets[0];
+  FW_CHECK_ARG(P >= 1, "prompts must not be empty");
+  for (int b = 0; b < B; ++b)
+    FW_CHECK_ARG(prompt_offsets[b + 1] - prompt_offsets[b] == P,
+                 "all prompts of a generate() call must have the same length (prompt %d has %d tokens, expected %d)",
+                 b, prompt_offsets[b + 1] - prompt_offsets[b], P);
+  FW_CHECK_ARG(P <= c.n_text_ctx, "prompt length %d exceeds the text context %d", P, c.n_text_ctx);
+  for (int i = 0; i < B * P; ++i)
+    FW_CHECK_ARG(prompts[i] >= 0 && prompts[i] < c.n_vocab, "prompt token %d out of range", prompts[i]);
+  int budget = max_new_tokens(std::min(o->max_length, c.n_text_ctx), P);
+  const int nh = o->num_hypotheses;
+  const int ml = o->max_length;
+  for (int i = 0; i < B * nh; ++i) { out_lens[i] = 0; out_scores[i] = 0.f; }
+  for (int b = 0; b < B; ++b) out_no_speech[b] = 0.f;
+
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  int rc;
+  if ((rc = ensure_cross_kv(m, enc))) return rc;
+
+  GenDev gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.B = B; gp.K = K; gp.R = B * K; gp.P = P; gp.budget = budget;
+  gp.max_fin = std::max(1, (int)lroundf((float)K * o->patience));
+  if (gp.max_fin > FIN_CAP - K) gp.max_fin = FIN_CAP - K;
+  gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
+  bool has_no_ts = false;
+  int sot_pos = -1;
+  for (int i = 0; i < P; ++i) {
+    if (prompts[i] == c.tok_no_timestamps) has_no_ts = true;
+    if (prompts[i] == c.tok_sot) sot_pos = i;
+  }
+  gp.with_ts = has_no_ts ? 0 : 1;
+  gp.suppress_blank = o->suppress_blank ? 1 : 0;
+  gp.min_new = o->min_new_tokens;
+  gp.mits = o->max_initial_timestamp_index;
+  gp.ngram = o->no_repeat_ngram_size;
+  gp.rep_pen = o->repetition_penalty;
+  gp.lp_pow = o->length_penalty;
+  gp.eot = c.tok_eot; gp.no_ts = c.tok_no_timestamps; gp.ts_begin = c.tok_timestamp_begin;
+  gp.n_sup_begin = c.n_suppress_begin;
+  for (int i = 0; i < c.n_suppress_begin; ++i) gp.sup_begin[i] = c.suppress_begin[i];
+
+  // ---- state init ----
+  const size_t R = (size_t)g->R, NT = g->NT;
+  FW_HIP(hipMemsetAsync(g->hist2, 0, 2 * R * NT * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * R * NT, st));
+  FW_HIP(hipMemsetAsync(g->cum2, 0, 2 * R * sizeof(float), st));
+  FW_HIP(hipMemsetAsync(g->done, 0, g->B * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->n_done, 0, sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->n_fin, 0, g->B * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->no_speech, 0, g->B * sizeof(float), st));
+  {
+    std::vector<uint8_t> mask(c.n_vocab, 0);
+    for (int i = 0; i < o->n_suppress_tokens; ++i) {
+      const int t = o->suppress_tokens[i];
+      if (t >= 0 && t < c.n_vocab) mask[t] = 1;
+    }
+    FW_HIP(hipMemcpyAsync(g->sup_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
+    FW_HIP(hipStreamSynchronize(st));  // mask is a stack-local buffer
+  }
+  // prompt tokens transposed to [pos][b]; first-step tokens replicated per beam
+  std::vector<int> ptok((size_t)P * B), first((size_t)B * K);
+  for (int b = 0; b < B; ++b)
+    for (int p = 0; p < P; ++p) ptok[(size_t)p * B + b] = prompts[prompt_offsets[b] + p];
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < K; ++k) first[(size_t)b * K + k] = prompts[prompt_offsets[b] + P - 1];
+  FW_HIP(hipMemcpyAsync(g->prompt_dev, ptok.data(), ptok.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  FW_HIP(hipMemcpyAsync(g->cur_tok, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  FW_HIP(hipStreamSynchronize(st));
+
+  // ---- prompt forward (all but the last token): B rows, beam slot 0 of every chunk ----
+  for (int pos = 0; pos < P - 1; ++pos) {
+    StepCfg s;
+    s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = pos; s.P = P; s.tok = g->prompt_dev + (size_t)pos * B;
+    s.need_logits = (pos == sot_pos) && o->return_no_speech_prob;
+    s.nospeech_rowmul = s.need_logits ? 1 : 0;
+    s.beam_tail = false;
+    s.done = g->done;
+    if ((rc = run_step(m, gp, s))) return rc;
+  }
+  if ((rc = check_launch("prompt forward"))) return rc;
+
+  int steps_done = 0;
+  if (budget > 0) {
+    // ---- step 0 (eager): last prompt token on all R rows; beams are identical copies ----
+    StepCfg s;
+    s.rows = B * K; s.kmul = K; s.B = B; s.pos_fixed = -1; s.P = P; s.tok = g->cur_tok;
+    s.need_logits = true;
+    s.nospeech_rowmul = (sot_pos == P - 1 && o->return_no_speech_prob) ? K : 0;
+    s.beam_tail = true;
+    s.done = g->done;
+    if ((rc = run_step(m, gp, s))) return rc;
+    steps_done = 1;
+    s.nospeech_rowmul = 0;
+
+    // ---- steps 1.. : one hipGraph replay per step ----
+    bool use_graph = g->graphs_enabled && !m->prof_on;
+    if (use_graph && !(g->graph_valid && memcmp(&g->graph_key, &gp, sizeof(gp)) == 0)) {
+      if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+      g->graph_valid = false;
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        int rc2 = run_step(m, gp, s);
+        hipError_t e2 = hipStreamEndCapture(st, &graph);
+        if (rc2 == FW_OK && e2 == hipSuccess && graph &&
+            hipGraphInstantiate(&g->graph, graph, nullptr, nullptr, 0) == hipSuccess) {
+          g->graph_valid = true;
+          g->graph_key = gp;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+      if (!g->graph_valid) use_graph = false;
+    }
+    int n_done_host = 0;
+    while (steps_done < budget) {
+      const int burst = std::min(4, budget - steps_done);
+      for (int i = 0; i < burst; ++i) {
+        if (use_graph) {
+          hipError_t he = hipGraphLaunch(g->graph, st);
+          if (he != hipSuccess) {
+            set_error("hipGraphLaunch failed: %s", hipGetErrorString(he));
+            return FW_ERUNTIME;
+          }
+        } else if ((rc = run_step(m, gp, s))) {
+          return rc;
+        }
+      }
+      steps_done += burst;
+      FW_HIP(hipMemcpyAsync(&n_done_host, g->n_done, sizeof(int), hipMemcpyDeviceToHost, st));
+      FW_HIP(hipStreamSynchronize(st));
+      if (n_done_host >= B) break;
+    }
+  }
+  FW_HIP(hipStreamSynchronize(st));
+  if ((rc = check_launch("decode loop"))) return rc;
+  prof_collect(m);
+
+  // ---- finalize on the host: best num_hypotheses by normalised score (stable) ----
+  std::vector<int> n_fin(B), fin_len((size_t)B * FIN_CAP);
+  std::vector<float> fin_score((size_t)B * FIN_CAP), nsp(B);
+  std::vector<int> fin_tok((size_t)B * FIN_CAP * NT);
+  FW_HIP(hipMemcpy(n_fin.data(), g->n_fin, B * sizeof(int), hipMemcpyDeviceToHost));
+  FW_HIP(hipMemcpy(fin_len.data(), g->fin_len, fin_len.size() * sizeof(int), hipMemcpyDeviceToHost));
+  FW_HIP(hipMemcpy(fin_score.data(), g->fin_score, fin_score.size() * sizeof(float), hipMemcpyDeviceToHost));
+  FW_HIP(hipMemcpy(fin_tok.data(), g->fin_tok, fin_tok.size() * sizeof(int), hipMemcpyDeviceToHost));
+  FW_HIP(hipMemcpy(nsp.data(), g->no_speech, B * sizeof(float), hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b) {
+    if (o->return_no_speech_prob) out_no_speech[b] = nsp[b];
+    std::vector<int> order(n_fin[b]);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int bb) {
+      return fin_score[(size_t)b * FIN_CAP + a] > fin_score[(size_t)b * FIN_CAP + bb];
+    });
+    for (int h = 0; h < nh && h < (int)order.size(); ++h) {
+      const int f = order[h];
+      int len = fin_len[(size_t)b * FIN_CAP + f];
+      if (len > ml) len = ml;
+      out_lens[b * nh + h] = len;
+      if (o->return_scores) out_scores[b * nh + h] = fin_score[(size_t)b * FIN_CAP + f];
+      memcpy(out_ids + ((size_t)b * nh + h) * ml, &fin_tok[((size_t)b * FIN_CAP + f) * NT], (size_t)len * sizeof(int));
+    }
+  }
+  return FW_OK;
+}
+
+int32_t fw_detect_language(fw_model* fm, const fw_tensor* enc_t, int32_t B, int32_t* out_lang_ids,
+                           float* out_probs) {
+  FW_CHECK_ARG(fm && enc_t && out_lang_ids && out_probs, "null argument");
+  Model* m = &fm->impl;
+  const Tensor* enc = &enc_t->impl;
+  GenWorkspace* g = m->gen;
+  const fw_config& c = m->cfg;
+  FW_CHECK_ARG(c.is_multilingual && c.n_langs > 0, "detect_language needs a multilingual model");
+  FW_CHECK_ARG(enc->owner == m && B == enc->B && B <= m->max_batch, "bad encoder output / batch");
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  int rc;
+  if ((rc = ensure_cross_kv(m, enc))) return rc;
+  GenDev gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = 1; gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
+  std::vector<int> tok(B, c.tok_sot);
+  FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * (size_t)g->R * g->NT, st));
+  FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
+  FW_HIP(hipMemcpyAsync(g->prompt_dev, tok.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+  FW_HIP(hipStreamSynchronize(st));
+  StepCfg s;
+  s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = 0; s.P = 1; s.tok = g->prompt_dev;
+  s.need_logits = true; s.nospeech_rowmul = 0; s.beam_tail = false; s.done = g->zero_done;
+  // rows of a prefill-style step use beam slot 0 of chunk b: slot stride is max_beam
+  if ((rc = run_step(m, gp, s))) return rc;
+  std::vector<float> lg((size_t)B * c.n_langs);
+  FW_HIP(hipMemcpy2DAsync(lg.data(), c.n_langs * sizeof(float), g->logits + c.tok_lang_begin,
+                          (size_t)c.n_vocab * sizeof(float), c.n_langs * sizeof(float), B, hipMemcpyDeviceToHost, st));
+  FW_HIP(hipStreamSynchronize(st));
+  if ((rc = check_launch("detect_language"))) return rc;
+  prof_collect(m);
+  for (int b = 0; b < B; ++b) {
+    const float* r = &lg[(size_t)b * c.n_langs];
+    float mx = r[0];
+    for (int i = 1; i < c.n_langs; ++i) mx = std::max(mx, r[i]);
+    std::vector<float> p(c.n_langs);
+    float sum = 0.f;
+    for (int i = 0; i < c.n_langs; ++i) { p[i] = expf(r[i] - mx); sum += p[i]; }
+    for (int i = 0; i < c.n_langs; ++i) p[i] /= sum;
+    std::vector<int> order(c.n_langs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int bb) { return p[a] > p[bb]; });
+    for (int i = 0; i < c.n_langs; ++i) {
+      out_lang_ids[(size_t)b * c.n_langs + i] = c.tok_lang_begin + order[i];
+      out_probs[(size_t)b * c.n_langs + i] = p[order[i]];
+    }
+  }
+  return FW_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// align: standardise over tokens, median filter over frames, mean over heads (device),
+// DTW (host, like CTranslate2).
+// ------------------------------------------------------------------------------------
+__global__ void align_stats_kernel(const float* __restrict__ probs, int n_sel, int n_tok_cap, int T,
+                                   const int* __restrict__ n_tok, const int* __restrict__ nfr,
+                                   float* __restrict__ stats) {
+  const int b = blockIdx.z, hs = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nfr[b]) return;
+  const int n = n_tok[b];
+  const float* p = probs + (((size_t)b * n_sel + hs) * n_tok_cap) * T + t;
+  float mean = 0.f;
+  for (int i = 0; i < n; ++i) mean += p[(size_t)i * T];
+  mean /= (float)n;
+  float var = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float dlt = p[(size_t)i * T] - mean;
+    var += dlt * dlt;
+  }
+  var /= (float)n;
+  float* so = stats + (((size_t)b * n_sel + hs) * T + t) * 2;
+  so[0] = mean;
+  so[1] = 1.0f / sqrtf(var);
+}
+
+__global__ void align_filter_kernel(const float* __restrict__ probs, const float* __restrict__ stats, int n_sel,
+                                    int n_tok_cap, int T, const int* __restrict__ n_tok, const int* __restrict__ nfr,
+                                    int width, float* __restrict__ out) {
+  const int b = blockIdx.z, tok = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int F = nfr[b];
+  if (t >= F || tok >= n_tok[b]) return;
+  const int pad = width / 2;
+  float acc = 0.f;
+  for (int hs = 0; hs < n_sel; ++hs) {
+    const float* p = probs + (((size_t)b * n_sel + hs) * n_tok_cap + tok) * T;
+    const float* st = stats + ((size_t)b * n_sel + hs) * T * 2;
+    float w[15];
+    const bool filt = pad > 0 && F > pad;
+    const int wd = filt ? width : 1;
+    for (int i = 0; i < wd; ++i) {
+      int tt = filt ? t - pad + i : t;
+      if (tt < 0) tt = -tt;                    // reflect padding
+      if (tt >= F) tt = 2 * (F - 1) - tt;
+      w[i] = (p[tt] - st[2 * tt]) * st[2 * tt + 1];
+    }
+    for (int i = 1; i < wd; ++i) {             // insertion sort (width <= 15)
+      const float v = w[i];
+      int q = i - 1;
+      while (q >= 0 && w[q] > v) { w[q + 1] = w[q]; --q; }
+      w[q + 1] = v;
+    }
+    acc += w[filt ? pad : 0];
+  }
+  out[((size_t)b * n_tok_cap + tok) * T + t] = acc / (float)n_sel;
+}
+
+namespace fw {
+// openai-whisper timing.dtw_cpu on cost = -matrix (N text rows x M frames)
+static void dtw_path(const float* mat, int ld, int N, int M, std::vector<int>& ti, std::vector<int>& fi) {
+  std::vector<double> D((size_t)(N + 1) * (M + 1), INFINITY);
+  std::vector<int8_t> tr((size_t)(N + 1) * (M + 1), -1);
+  auto at = [&](int i, int j) -> size_t { return (size_t)i * (M + 1) + j; };
+  D[at(0, 0)] = 0;
+  for (int j = 1; j <= M; ++j)
+    for (int i = 1; i <= N; ++i) {
+      const double c0 = D[at(i - 1, j - 1)], c1 = D[at(i - 1, j)], c2 = D[at(i, j - 1)];
+      double cc; int8_t t;
+      if (c0 < c1 && c0 < c2) { cc = c0; t = 0; }
+      else if (c1 < c0 && c1 < c2) { cc = c1; t = 1; }
+      else { cc = c2; t = 2; }
+      D[at(i, j)] = -(double)mat[(size_t)(i - 1) * ld + (j - 1)] + cc;
+      tr[at(i, j)] = t;
+    }
+  for (int j = 0; j <= M; ++j) tr[at(0, j)] = 2;
+  for (int i = 0; i <= N; ++i) tr[at(i, 0)] = 1;
+  int i = N, j = M;
+  ti.clear(); fi.clear();
+  while (i > 0 || j > 0) {
+    ti.push_back(i - 1); fi.push_back(j - 1);
+    const int8_t t = tr[at(i, j)];
+    if (t == 0) { --i; --j; }
+    else if (t == 1) { --i; }
+    else { --j; }
+  }
+  std::reverse(ti.begin(), ti.end());
+  std::reverse(fi.begin(), fi.end());
+}
+}  // namespace fw
+
+extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t* start_seq, int32_t n_start,
+                            const int32_t* text_tokens, const int32_t* text_offsets, const int32_t* num_frames,
+                            int32_t B, int32_t median_filter_width, int32_t max_pairs, int32_t* out_pairs,
+                            int32_t* out_n_pairs, float* out_probs) {
+  FW_CHECK_ARG(fm && enc_t && start_seq && text_tokens && text_offsets && num_frames && out_pairs && out_n_pairs &&
+                   out_probs, "null argument");
+  Model* m = &fm->impl;
+  const Tensor* enc = &enc_t->impl;
+  GenWorkspace* g = m->gen;
+  const fw_config& c = m->cfg;
+  FW_CHECK_ARG(enc->owner == m && B == enc->B && B <= m->max_batch, "bad encoder output / batch");
+  FW_CHECK_ARG(n_start >= 1, "start_sequence must not be empty");
+  FW_CHECK_ARG(median_filter_width >= 1 && median_filter_width <= 15 && (median_filter_width & 1),
+               "median_filter_width must be odd and <= 15");
+  const int T = c.n_audio_ctx, d = c.d_model;
+  // teacher-forced sequences: start + no_timestamps + text + eot
+  std::vector<std::vector<int>> seq(B);
+  int max_tok = 0;
+  for (int b = 0; b < B; ++b) {
+    const int nt = text_offsets[b + 1] - text_offsets[b];
+    FW_CHECK_ARG(nt >= 0, "bad text offsets");
+    for (int i = 0; i < n_start; ++i) seq[b].push_back(start_seq[i]);
+    seq[b].push_back(c.tok_no_timestamps);
+    for (int i = 0; i < nt; ++i) {
+      const int t = text_tokens[text_offsets[b] + i];
+      FW_CHECK_ARG(t >= 0 && t < c.n_vocab, "text token %d out of range", t);
+      seq[b].push_back(t);
+    }
+    seq[b].push_back(c.tok_eot);
+    FW_CHECK_ARG((int)seq[b].size() <= c.n_text_ctx, "align sequence of %zu tokens exceeds the text context", seq[b].size());
+    max_tok = std::max(max_tok, (int)seq[b].size());
+  }
+  // alignment heads grouped per layer
+  std::vector<std::vector<int>> per_layer(c.n_dec_layers);
+  if (c.n_align_heads > 0) {
+    for (int i = 0; i < c.n_align_heads; ++i) {
+      const int l = c.align_heads[2 * i], h = c.align_heads[2 * i + 1];
+      FW_CHECK_ARG(l >= 0 && l < c.n_dec_layers && h >= 0 && h < c.n_heads, "alignment head (%d,%d) out of range", l, h);
+      per_layer[l].push_back(h);
+    }
+  } else {  // [CT2-ext] default: all heads of the upper half of the decoder
+    for (int l = c.n_dec_layers / 2; l < c.n_dec_layers; ++l)
+      for (int h = 0; h < c.n_heads; ++h) per_layer[l].push_back(h);
+  }
+  std::vector<int> sel_heads, layer_off(c.n_dec_layers + 1, 0);
+  for (int l = 0; l < c.n_dec_layers; ++l) {
+    layer_off[l] = (int)sel_heads.size();
+    for (int h : per_layer[l]) sel_heads.push_back(h);
+  }
+  layer_off[c.n_dec_layers] = (int)sel_heads.size();
+  const int n_sel = (int)sel_heads.size();
+  FW_CHECK_ARG(n_sel > 0, "no alignment heads");
+
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  int rc;
+  if ((rc = ensure_cross_kv(m, enc))) return rc;
+
+  float *probs = nullptr, *stats = nullptr, *mat = nullptr, *tprob = nullptr;
+  int *heads_dev = nullptr, *ntok_dev = nullptr, *nfr_dev = nullptr, *target_dev = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)probs, (void*)stats, (void*)mat, (void*)tprob, (void*)heads_dev, (void*)ntok_dev,
+                    (void*)nfr_dev, (void*)target_dev})
+      if (p) (void)hipFree(p);
+  };
+#define AL(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) { cleanup(); return rc; } } while (0)
+  AL(probs, (size_t)B * n_sel * max_tok * T);
+  AL(stats, (size_t)B * n_sel * T * 2);
+  AL(mat, (size_t)B * max_tok * T);
+  AL(tprob, (size_t)B * max_tok);
+  AL(heads_dev, (size_t)n_sel);
+  AL(ntok_dev, (size_t)B); AL(nfr_dev, (size_t)B);
+  AL(target_dev, (size_t)max_tok * B);
+#undef AL
+  std::vector<int> ntok(B), nfr(B), ptok((size_t)max_tok * B), target((size_t)max_tok * B, -1);
+  for (int b = 0; b < B; ++b) {
+    ntok[b] = (int)seq[b].size();
+    nfr[b] = std::min(T, std::max(1, num_frames[b] / 2));
+    for (int p = 0; p < max_tok; ++p) {
+      ptok[(size_t)p * B + b] = p < ntok[b] ? seq[b][p] : c.tok_eot;
+      // the logits at position p predict token p+1; we want probs of the text tokens only
+      const int n0 = n_start + 1;
+      const int nt = ntok[b] - n0 - 1;
+      if (p >= n0 - 1 && p < n0 - 1 + nt) target[(size_t)p * B + b] = seq[b][p + 1];
+    }
+  }
+  hipError_t he = hipMemcpyAsync(heads_dev, sel_heads.data(), n_sel * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(ntok_dev, ntok.data(), B * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(nfr_dev, nfr.data(), B * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess)
+    he = hipMemcpyAsync(g->prompt_dev, ptok.data(), ptok.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess)
+    he = hipMemcpyAsync(target_dev, target.data(), target.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemsetAsync(g->kvidx2, 0, 2 * (size_t)g->R * g->NT, st);
+  if (he == hipSuccess) he = hipMemsetAsync(g->d_step, 0, sizeof(int), st);
+  if (he == hipSuccess) he = hipMemsetAsync(tprob, 0, (size_t)B * max_tok * sizeof(float), st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he != hipSuccess) {
+    cleanup();
+    set_error("align setup failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  GenDev gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = max_tok; gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
+  for (int pos = 0; pos < max_tok; ++pos) {
+    StepCfg s;
+    s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = pos; s.P = max_tok; s.tok = g->prompt_dev + (size_t)pos * B;
+    bool any_target = false;
+    for (int b = 0; b < B; ++b) any_target |= target[(size_t)pos * B + b] >= 0;
+    s.need_logits = any_target;
+    s.nospeech_rowmul = 0; s.beam_tail = false; s.done = g->zero_done;
+    s.sel_heads_dev = heads_dev; s.sel_layer_off = layer_off.data(); s.probs = probs; s.n_sel_total = n_sel;
+    s.n_tok = max_tok; s.tok_idx = pos;
+    if ((rc = run_step(m, gp, s))) { cleanup(); return rc; }
+    if (any_target)
+      fwd::launch_token_prob(st, g->logits, c.n_vocab, target_dev + (size_t)pos * B, tprob, max_tok, pos, B);
+  }
+  {
+    dim3 g1((T + 127) / 128, n_sel, B);
+    align_stats_kernel<<<g1, 128, 0, st>>>(probs, n_sel, max_tok, T, ntok_dev, nfr_dev, stats);
+    dim3 g2((T + 127) / 128, max_tok, B);
+    align_filter_kernel<<<g2, 128, 0, st>>>(probs, stats, n_sel, max_tok, T, ntok_dev, nfr_dev, median_filter_width,
+                                             mat);
+  }
+  std::vector<float> hmat((size_t)B * max_tok * T), htprob((size_t)B * max_tok);
+  he = hipMemcpyAsync(hmat.data(), mat, hmat.size() * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(htprob.data(), tprob, htprob.size() * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he == hipSuccess) he = hipGetLastError();
+  cleanup();
+  if (he != hipSuccess) {
+    set_error("align failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  prof_collect(m);
+  const int n0 = n_start + 1;
+  for (int b = 0; b < B; ++b) {
+    const int nt = ntok[b] - n0 - 1;
+    out_n_pairs[b] = 0;
+    for (int i = 0; i < nt; ++i) out_probs[text_offsets[b] + i] = htprob[(size_t)b * max_tok + (n0 - 1 + i)];
+    if (nt <= 0) continue;
+    std::vector<int> ti, fi;
+    fw::dtw_path(&hmat[((size_t)b * max_tok + n0) * T], T, nt, nfr[b], ti, fi);
+    const int np = std::min((int)ti.size(), max_pairs);
+    for (int i = 0; i < np; ++i) {
+      out_pairs[((size_t)b * max_pairs + i) * 2] = ti[i];
+      out_pairs[((size_t)b * max_pairs + i) * 2 + 1] = fi[i];
+    }
+    out_n_pairs[b] = np;
+  }
+  return FW_OK;
+}

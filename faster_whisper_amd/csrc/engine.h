@@ -1,0 +1,171 @@
+// Engine-internal structures of libfwamd.so (host side, C++17).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fwamd.h"
+#include "common.h"
+
+namespace fw {
+
+void set_error(const char* fmt, ...);
+#define FW_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      fw::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return FW_ENODEV;                                                                \
+    }                                                                                  \
+  } while (0)
+#define FW_CHECK_ARG(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      fw::set_error(__VA_ARGS__);      \
+      return FW_EINVAL;                \
+    }                                  \
+  } while (0)
+
+// ---- weight blob (what travels over RCCL at load time) --------------------------------
+#define FW_BLOB_MAGIC "FWAMDBL1"
+struct BlobHeader {
+  char magic[8];
+  int32_t version;
+  int32_t n_tensors;
+  int64_t total_bytes;
+  int32_t compute_type;
+  int32_t reserved;
+  fw_config cfg;
+};
+struct BlobEntry {
+  char name[64];
+  int32_t dtype;  // 1 = f16, 2 = i8, 0 = f32
+  int32_t ndim;
+  int64_t dims[4];
+  int64_t offset;  // from blob start, 256-byte aligned
+  int64_t nbytes;
+};
+
+struct DevTensor {
+  void* ptr = nullptr;
+  int dtype = 1;
+  int ndim = 0;
+  int64_t dims[4] = {0, 0, 0, 0};
+};
+
+struct LinearW {           // y = x W^T + b ; W [N][K] fp16 (or int8 + per-row scale)
+  const half_t* w = nullptr;
+  const half_t* b = nullptr;
+  const int8_t* wq = nullptr;    // int8 weights [N][K]           (int8_float16 only)
+  const float* wscale = nullptr; // dequant scale per output row  (int8_float16 only)
+  int N = 0, K = 0;
+};
+struct LNW { const half_t* g = nullptr; const half_t* b = nullptr; };
+
+struct EncLayerW { LNW ln1, ln2; LinearW qk, v, out, ffn1, ffn2; };
+struct DecLayerW { LNW ln1, ln2, ln3; LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };
+
+enum ProfFamily {
+  PF_LOGMEL = 0, PF_ENC_GEMM, PF_ENC_ATTN, PF_ENC_LN, PF_CROSS_KV_GEMM,
+  PF_DEC_GEMM, PF_DEC_SELF_ATTN, PF_DEC_CROSS_ATTN, PF_DEC_LOGITS, PF_DEC_SAMPLE, PF_DEC_MISC, PF_COUNT
+};
+
+struct ProfAcc {
+  double ms = 0; int64_t launches = 0; double flops = 0; double bytes = 0;
+};
+
+struct Model;
+struct Tensor {  // fw_tensor
+  Model* owner = nullptr;
+  half_t* data = nullptr;  // [B][T][D] fp16, device
+  int B = 0, T = 0, D = 0;
+  uint64_t id = 0;         // unique per encoder output (cross-K/V cache key)
+};
+
+struct GenWorkspace;  // decoder-side buffers (decoder.hip)
+
+struct Model {
+  fw_config cfg{};
+  int compute_type = 0;
+  int device = 0;
+  int max_batch = 0, max_beam = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+
+  // weights
+  void* blob = nullptr;     // device blob (owned unless external)
+  bool blob_owned = true;
+  int64_t blob_bytes = 0;
+  std::map<std::string, DevTensor> tensors;
+  int c_pad = 0;  // mel channels padded to a multiple of 64 for the conv1 GEMM
+  LinearW conv1, conv2;
+  const half_t* enc_pos = nullptr;
+  std::vector<EncLayerW> enc;
+  LNW enc_ln_post;
+  const half_t* tok_emb = nullptr;  // [V][d]
+  const half_t* dec_pos = nullptr;  // [n_text_ctx][d]
+  std::vector<DecLayerW> dec;
+  LNW dec_ln;
+
+  // log-mel constants
+  float* lm_consts = nullptr;  // cos table [400] + hann [400]
+  float* lm_filtT = nullptr;   // [224][mel_pad]
+  int lm_mel_pad = 0;
+
+  // encoder workspaces (sized for max_batch)
+  float* ws_pcm = nullptr; int64_t ws_pcm_cap = 0;
+  int64_t* ws_offsets = nullptr;
+  float* ws_raw = nullptr; int64_t ws_raw_cap = 0;   // raw log-mel
+  int* ws_chunk_max = nullptr;
+  int* ws_nframes = nullptr;
+  float* ws_feat32 = nullptr;                         // [B][n_mels][3000]
+  half_t* ws_mel_cl = nullptr;                        // [B][3002][c_pad]
+  half_t* ws_conv1 = nullptr;                         // [B][3002][d]
+  half_t *ws_x = nullptr, *ws_x2 = nullptr, *ws_xn = nullptr;  // [B][1500][d]
+  half_t* ws_qk = nullptr;                            // [B][1500][2d]
+  half_t* ws_vt = nullptr;                            // [B][d][t_pad]
+  half_t* ws_att = nullptr;                           // [B][1500][d]
+  half_t* ws_ffn = nullptr;                           // [B][1500][4d]
+  int t_pad = 0;
+
+  GenWorkspace* gen = nullptr;
+
+  // profiling
+  bool prof_on = false;
+  ProfAcc prof[PF_COUNT];
+  struct PendingEv { hipEvent_t a, b; int fam; };
+  std::vector<PendingEv> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+// profiling scope: brackets a group of launches with HIP events on the model's stream
+struct ProfScope {
+  Model* m; int fam; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(Model* m_, int fam_, double flops, double bytes);
+  ~ProfScope();
+};
+void prof_collect(Model* m);
+
+int dev_alloc(void** p, size_t bytes);
+template <typename T>
+inline int dev_alloc_t(T** p, size_t n) { return dev_alloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
+
+// linear layer on "many rows": C = act(A W^T + b) + res   (encoder / prefill / align)
+int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t a_bs, half_t* C, int64_t ldc,
+               int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans);
+
+// encoder forward on the channel-last mel image already in m->ws_mel_cl; result into out [B][1500][d]
+int run_encoder(Model* m, int B, half_t* out);
+
+// decoder entry points (decoder.hip)
+uint64_t next_tensor_id();
+int gen_workspace_create(Model* m);
+void gen_workspace_free(Model* m);
+
+}  // namespace fw
+
+struct fw_model { fw::Model impl; };
+struct fw_tensor { fw::Tensor impl; };

@@ -1,0 +1,1068 @@
+// libfwamd.so — host side of the MI355X Whisper engine: C ABI (include/fwamd.h), weight
+// packing/upload, workspaces, the log-mel + encoder pipeline and the kernel test hooks.
+// The decoder / generate / align side lives in decoder.hip.
+//
+// Reference interfaces replaced here (faster_whisper/transcribe.py): the
+// ctranslate2.models.Whisper constructor (:689-698), .encode (:1400), the
+// numpy FeatureExtractor call on the host (:463-467) and StorageView.from_array (:1875).
+#include "engine.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace fw {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int dev_alloc(void** p, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    *p = nullptr;
+    return FW_ENOMEM;
+  }
+  return FW_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+static const char* kProfNames[PF_COUNT] = {
+    "logmel", "enc_gemm", "enc_attn", "enc_layernorm", "cross_kv_gemm", "dec_gemm",
+    "dec_self_attn", "dec_cross_attn", "dec_logits", "dec_sample", "dec_misc"};
+
+static hipEvent_t ev_get(Model* m) {
+  if (!m->ev_pool.empty()) {
+    hipEvent_t e = m->ev_pool.back();
+    m->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+ProfScope::ProfScope(Model* m_, int fam_, double flops, double bytes) : m(m_), fam(fam_) {
+  if (!m->prof_on) return;
+  a = ev_get(m);
+  b = ev_get(m);
+  m->prof[fam].flops += flops;
+  m->prof[fam].bytes += bytes;
+  m->prof[fam].launches += 1;
+  (void)hipEventRecord(a, m->stream);
+}
+ProfScope::~ProfScope() {
+  if (!a) return;
+  (void)hipEventRecord(b, m->stream);
+  m->pending.push_back({a, b, fam});
+}
+void prof_collect(Model* m) {
+  for (auto& p : m->pending) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, p.a, p.b);
+    m->prof[p.fam].ms += ms;
+    m->ev_pool.push_back(p.a);
+    m->ev_pool.push_back(p.b);
+  }
+  m->pending.clear();
+}
+
+// ---------------------------------------------------------------- fp16 helpers (host)
+static inline uint16_t f32_to_f16_bits(float f) {
+  half_t h = (half_t)f;  // round-to-nearest-even, same as the device cast
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+
+// ---------------------------------------------------------------- blob packing
+struct PackItem {
+  std::string name;
+  int ndim;
+  int64_t dims[4];
+  std::vector<uint16_t> data;  // fp16 payload
+};
+
+static const fw_weight* find_w(const fw_weight* w, int n, const std::string& name) {
+  for (int i = 0; i < n; ++i)
+    if (name == w[i].name) return &w[i];
+  return nullptr;
+}
+static int64_t numel(const fw_weight* w) {
+  int64_t n = 1;
+  for (int i = 0; i < w->ndim; ++i) n *= w->dims[i];
+  return n;
+}
+static float w_at(const fw_weight* w, int64_t i) {
+  if (w->dtype == FW_DT_F32) return reinterpret_cast<const float*>(w->data)[i];
+  half_t h;
+  memcpy(&h, reinterpret_cast<const uint16_t*>(w->data) + i, 2);
+  return (float)h;
+}
+static void to_f16(const fw_weight* w, std::vector<uint16_t>& out) {
+  const int64_t n = numel(w);
+  out.resize(n);
+  if (w->dtype == FW_DT_F16) {
+    memcpy(out.data(), w->data, n * 2);
+  } else {
+    const float* s = reinterpret_cast<const float*>(w->data);
+    for (int64_t i = 0; i < n; ++i) out[i] = f32_to_f16_bits(s[i]);
+  }
+}
+
+static int expect_shape(const fw_weight* w, const std::string& name, std::initializer_list<int64_t> dims) {
+  if (!w) {
+    set_error("missing weight '%s'", name.c_str());
+    return FW_EINVAL;
+  }
+  if ((size_t)w->ndim != dims.size()) {
+    set_error("weight '%s': expected %zu dims, got %d", name.c_str(), dims.size(), w->ndim);
+    return FW_EINVAL;
+  }
+  int i = 0;
+  for (int64_t d : dims) {
+    if (w->dims[i] != d) {
+      set_error("weight '%s': dim %d is %lld, expected %lld", name.c_str(), i, (long long)w->dims[i], (long long)d);
+      return FW_EINVAL;
+    }
+    ++i;
+  }
+  return FW_OK;
+}
+
+static int check_config(const fw_config* c) {
+  FW_CHECK_ARG(c->n_mels > 0 && c->n_mels <= 128, "n_mels must be in (0,128], got %d", c->n_mels);
+  FW_CHECK_ARG(c->d_model % 128 == 0 && c->d_model >= 128 && c->d_model <= 1280,
+               "d_model must be a multiple of 128 in [128,1280], got %d", c->d_model);
+  FW_CHECK_ARG(c->n_heads * 64 == c->d_model, "head dim must be 64 (n_heads=%d, d_model=%d)", c->n_heads, c->d_model);
+  FW_CHECK_ARG(c->n_audio_ctx == 1500, "n_audio_ctx must be 1500, got %d", c->n_audio_ctx);
+  FW_CHECK_ARG(c->n_text_ctx > 0 && c->n_text_ctx <= 448, "n_text_ctx must be in (0,448]");
+  FW_CHECK_ARG(c->n_enc_layers > 0 && c->n_dec_layers > 0, "layer counts must be positive");
+  FW_CHECK_ARG(c->n_vocab > c->tok_timestamp_begin && c->tok_timestamp_begin > 0, "bad vocabulary layout");
+  FW_CHECK_ARG(c->n_align_heads >= 0 && c->n_align_heads <= FW_MAX_ALIGN_HEADS, "too many alignment heads");
+  FW_CHECK_ARG(c->n_suppress_begin >= 0 && c->n_suppress_begin <= 8, "n_suppress_begin out of range");
+  return FW_OK;
+}
+
+// Build the device blob image on the host. All tensors fp16, final kernel layouts.
+static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compute_type,
+                     std::vector<uint8_t>& blob) {
+  const int d = cfg->d_model, nm = cfg->n_mels;
+  const int c_pad = ((nm + 63) / 64) * 64;
+  std::vector<PackItem> items;
+  auto add_plain = [&](const std::string& name, std::initializer_list<int64_t> dims) -> int {
+    const fw_weight* t = find_w(w, nw, name);
+    int rc = expect_shape(t, name, dims);
+    if (rc) return rc;
+    PackItem it;
+    it.name = name;
+    it.ndim = (int)dims.size();
+    int i = 0;
+    for (int64_t x : dims) it.dims[i++] = x;
+    for (; i < 4; ++i) it.dims[i] = 1;
+    to_f16(t, it.data);
+    items.push_back(std::move(it));
+    return FW_OK;
+  };
+  // conv weights [out][in][3] -> GEMM form [out][tap*cin_pad + cin]
+  auto add_conv = [&](const std::string& name, int cout, int cin, int cin_pad) -> int {
+    const fw_weight* t = find_w(w, nw, name + ".w");
+    int rc = expect_shape(t, name + ".w", {cout, cin, 3});
+    if (rc) return rc;
+    PackItem it;
+    it.name = name + ".wg";
+    it.ndim = 2;
+    it.dims[0] = cout; it.dims[1] = 3 * cin_pad; it.dims[2] = it.dims[3] = 1;
+    it.data.assign((size_t)cout * 3 * cin_pad, 0);
+    for (int o = 0; o < cout; ++o)
+      for (int c = 0; c < cin; ++c)
+        for (int k = 0; k < 3; ++k)
+          it.data[(size_t)o * 3 * cin_pad + (size_t)k * cin_pad + c] =
+              f32_to_f16_bits(w_at(t, ((int64_t)o * cin + c) * 3 + k));
+    items.push_back(std::move(it));
+    return add_plain(name + ".b", {cout});
+  };
+  int rc;
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+  TRY(add_conv("enc.conv1", d, nm, c_pad));
+  TRY(add_conv("enc.conv2", d, d, d));
+  TRY(add_plain("enc.pos", {cfg->n_audio_ctx, d}));
+  char nb[96];
+  for (int i = 0; i < cfg->n_enc_layers; ++i) {
+    auto nmf = [&](const char* s) { snprintf(nb, sizeof(nb), "enc.%d.%s", i, s); return std::string(nb); };
+    TRY(add_plain(nmf("ln1.g"), {d})); TRY(add_plain(nmf("ln1.b"), {d}));
+    TRY(add_plain(nmf("attn.qkv.w"), {3 * d, d})); TRY(add_plain(nmf("attn.qkv.b"), {3 * d}));
+    TRY(add_plain(nmf("attn.out.w"), {d, d})); TRY(add_plain(nmf("attn.out.b"), {d}));
+    TRY(add_plain(nmf("ln2.g"), {d})); TRY(add_plain(nmf("ln2.b"), {d}));
+    TRY(add_plain(nmf("ffn1.w"), {4 * d, d})); TRY(add_plain(nmf("ffn1.b"), {4 * d}));
+    TRY(add_plain(nmf("ffn2.w"), {d, 4 * d})); TRY(add_plain(nmf("ffn2.b"), {d}));
+  }
+  TRY(add_plain("enc.ln_post.g", {d})); TRY(add_plain("enc.ln_post.b", {d}));
+  TRY(add_plain("dec.tok_emb", {cfg->n_vocab, d}));
+  TRY(add_plain("dec.pos", {cfg->n_text_ctx, d}));
+  for (int i = 0; i < cfg->n_dec_layers; ++i) {
+    auto nmf = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
+    TRY(add_plain(nmf("ln1.g"), {d})); TRY(add_plain(nmf("ln1.b"), {d}));
+    TRY(add_plain(nmf("self.qkv.w"), {3 * d, d})); TRY(add_plain(nmf("self.qkv.b"), {3 * d}));
+    TRY(add_plain(nmf("self.out.w"), {d, d})); TRY(add_plain(nmf("self.out.b"), {d}));
+    TRY(add_plain(nmf("ln2.g"), {d})); TRY(add_plain(nmf("ln2.b"), {d}));
+    TRY(add_plain(nmf("cross.q.w"), {d, d})); TRY(add_plain(nmf("cross.q.b"), {d}));
+    TRY(add_plain(nmf("cross.kv.w"), {2 * d, d})); TRY(add_plain(nmf("cross.kv.b"), {2 * d}));
+    TRY(add_plain(nmf("cross.out.w"), {d, d})); TRY(add_plain(nmf("cross.out.b"), {d}));
+    TRY(add_plain(nmf("ln3.g"), {d})); TRY(add_plain(nmf("ln3.b"), {d}));
+    TRY(add_plain(nmf("ffn1.w"), {4 * d, d})); TRY(add_plain(nmf("ffn1.b"), {4 * d}));
+    TRY(add_plain(nmf("ffn2.w"), {d, 4 * d})); TRY(add_plain(nmf("ffn2.b"), {d}));
+  }
+  TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
+#undef TRY
+
+  const int64_t hdr = (int64_t)sizeof(BlobHeader) + (int64_t)items.size() * sizeof(BlobEntry);
+  int64_t off = (hdr + 255) / 256 * 256;
+  std::vector<BlobEntry> entries(items.size());
+  for (size_t i = 0; i < items.size(); ++i) {
+    BlobEntry& e = entries[i];
+    memset(&e, 0, sizeof(e));
+    snprintf(e.name, sizeof(e.name), "%s", items[i].name.c_str());
+    e.dtype = 1;
+    e.ndim = items[i].ndim;
+    for (int k = 0; k < 4; ++k) e.dims[k] = items[i].dims[k];
+    e.offset = off;
+    e.nbytes = (int64_t)items[i].data.size() * 2;
+    off = (off + e.nbytes + 255) / 256 * 256;
+  }
+  blob.assign((size_t)off, 0);
+  BlobHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, FW_BLOB_MAGIC, 8);
+  h.version = 1;
+  h.n_tensors = (int32_t)items.size();
+  h.total_bytes = off;
+  h.compute_type = compute_type;
+  h.cfg = *cfg;
+  memcpy(blob.data(), &h, sizeof(h));
+  memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
+  for (size_t i = 0; i < items.size(); ++i)
+    memcpy(blob.data() + entries[i].offset, items[i].data.data(), (size_t)entries[i].nbytes);
+  return FW_OK;
+}
+
+// ---------------------------------------------------------------- mel constants
+// get_mel_filters (feature_extractor.py:25-65), in double like numpy, stored float32.
+static void compute_mel_filters(int n_mels, std::vector<float>& filt /* [n_mels][201] */) {
+  const int n_fft = 400, nb = 201;
+  const double sr = 16000.0;
+  std::vector<double> fftfreqs(nb);
+  const double val = 1.0 / (n_fft * (1.0 / sr));
+  for (int k = 0; k < nb; ++k) fftfreqs[k] = k * val;
+  const double max_mel = 45.245640471924965;
+  const int n = n_mels + 2;
+  std::vector<double> mels(n), freqs(n);
+  const double step = (max_mel - 0.0) / (n - 1);
+  for (int i = 0; i < n; ++i) mels[i] = i * step + 0.0;
+  mels[n - 1] = max_mel;
+  const double f_sp = 200.0 / 3;
+  const double min_log_hz = 1000.0, min_log_mel = (min_log_hz - 0.0) / f_sp;
+  const double logstep = log(6.4) / 27.0;
+  for (int i = 0; i < n; ++i) {
+    freqs[i] = 0.0 + f_sp * mels[i];
+    if (mels[i] >= min_log_mel) freqs[i] = min_log_hz * exp(logstep * (mels[i] - min_log_mel));
+  }
+  filt.assign((size_t)n_mels * nb, 0.f);
+  for (int i = 0; i < n_mels; ++i) {
+    const double fd0 = freqs[i + 1] - freqs[i], fd1 = freqs[i + 2] - freqs[i + 1];
+    const double enorm = 2.0 / (freqs[i + 2] - freqs[i]);
+    for (int k = 0; k < nb; ++k) {
+      const double lower = -(freqs[i] - fftfreqs[k]) / fd0;
+      const double upper = (freqs[i + 2] - fftfreqs[k]) / fd1;
+      double wv = std::max(0.0, std::min(lower, upper));
+      wv *= enorm;
+      filt[(size_t)i * nb + k] = (float)wv;
+    }
+  }
+}
+
+static int setup_logmel_consts(Model* m) {
+  std::vector<float> consts(800);
+  for (int j = 0; j < 400; ++j) consts[j] = (float)cos(2.0 * M_PI * (double)j / 400.0);
+  // np.hanning(401)[:-1] : 0.5 - 0.5*cos(2*pi*n/(M-1)), M = 401
+  for (int n = 0; n < 400; ++n) consts[400 + n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / 400.0));
+  std::vector<float> filt;
+  compute_mel_filters(m->cfg.n_mels, filt);
+  m->lm_mel_pad = ((m->cfg.n_mels + 31) / 32) * 32;
+  std::vector<float> filtT((size_t)224 * m->lm_mel_pad, 0.f);
+  for (int i = 0; i < m->cfg.n_mels; ++i)
+    for (int k = 0; k < 201; ++k) filtT[(size_t)k * m->lm_mel_pad + i] = filt[(size_t)i * 201 + k];
+  int rc;
+  if ((rc = dev_alloc_t(&m->lm_consts, 800))) return rc;
+  if ((rc = dev_alloc_t(&m->lm_filtT, filtT.size()))) return rc;
+  FW_HIP(hipMemcpy(m->lm_consts, consts.data(), 800 * sizeof(float), hipMemcpyHostToDevice));
+  FW_HIP(hipMemcpy(m->lm_filtT, filtT.data(), filtT.size() * sizeof(float), hipMemcpyHostToDevice));
+  return FW_OK;
+}
+
+// ---------------------------------------------------------------- model construction
+static const half_t* tptr(Model* m, const std::string& name) {
+  auto it = m->tensors.find(name);
+  return it == m->tensors.end() ? nullptr : reinterpret_cast<const half_t*>(it->second.ptr);
+}
+
+static int bind_weights(Model* m) {
+  const fw_config& c = m->cfg;
+  const int d = c.d_model;
+  m->c_pad = ((c.n_mels + 63) / 64) * 64;
+  auto need = [&](const std::string& n, const half_t** out) -> int {
+    *out = tptr(m, n);
+    if (!*out) {
+      set_error("weight blob lacks tensor '%s'", n.c_str());
+      return FW_EINVAL;
+    }
+    return FW_OK;
+  };
+  int rc;
+#define NEED(n, p) do { if ((rc = need(n, p))) return rc; } while (0)
+  NEED("enc.conv1.wg", &m->conv1.w); NEED("enc.conv1.b", &m->conv1.b);
+  m->conv1.N = d; m->conv1.K = 3 * m->c_pad;
+  NEED("enc.conv2.wg", &m->conv2.w); NEED("enc.conv2.b", &m->conv2.b);
+  m->conv2.N = d; m->conv2.K = 3 * d;
+  NEED("enc.pos", &m->enc_pos);
+  m->enc.resize(c.n_enc_layers);
+  char nb[96];
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    EncLayerW& L = m->enc[i];
+    auto nm = [&](const char* s) { snprintf(nb, sizeof(nb), "enc.%d.%s", i, s); return std::string(nb); };
+    const half_t *qkvw, *qkvb;
+    NEED(nm("ln1.g"), &L.ln1.g); NEED(nm("ln1.b"), &L.ln1.b);
+    NEED(nm("attn.qkv.w"), &qkvw); NEED(nm("attn.qkv.b"), &qkvb);
+    L.qk = LinearW{qkvw, qkvb, nullptr, nullptr, 2 * d, d};
+    L.v = LinearW{qkvw + (size_t)2 * d * d, qkvb + 2 * d, nullptr, nullptr, d, d};
+    NEED(nm("attn.out.w"), &L.out.w); NEED(nm("attn.out.b"), &L.out.b); L.out.N = d; L.out.K = d;
+    NEED(nm("ln2.g"), &L.ln2.g); NEED(nm("ln2.b"), &L.ln2.b);
+    NEED(nm("ffn1.w"), &L.ffn1.w); NEED(nm("ffn1.b"), &L.ffn1.b); L.ffn1.N = 4 * d; L.ffn1.K = d;
+    NEED(nm("ffn2.w"), &L.ffn2.w); NEED(nm("ffn2.b"), &L.ffn2.b); L.ffn2.N = d; L.ffn2.K = 4 * d;
+  }
+  NEED("enc.ln_post.g", &m->enc_ln_post.g); NEED("enc.ln_post.b", &m->enc_ln_post.b);
+  NEED("dec.tok_emb", &m->tok_emb); NEED("dec.pos", &m->dec_pos);
+  m->dec.resize(c.n_dec_layers);
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    DecLayerW& L = m->dec[i];
+    auto nm = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
+    const half_t *kvw, *kvb;
+    NEED(nm("ln1.g"), &L.ln1.g); NEED(nm("ln1.b"), &L.ln1.b);
+    NEED(nm("self.qkv.w"), &L.qkv.w); NEED(nm("self.qkv.b"), &L.qkv.b); L.qkv.N = 3 * d; L.qkv.K = d;
+    NEED(nm("self.out.w"), &L.out.w); NEED(nm("self.out.b"), &L.out.b); L.out.N = d; L.out.K = d;
+    NEED(nm("ln2.g"), &L.ln2.g); NEED(nm("ln2.b"), &L.ln2.b);
+    NEED(nm("cross.q.w"), &L.cq.w); NEED(nm("cross.q.b"), &L.cq.b); L.cq.N = d; L.cq.K = d;
+    NEED(nm("cross.kv.w"), &kvw); NEED(nm("cross.kv.b"), &kvb);
+    L.ck = LinearW{kvw, kvb, nullptr, nullptr, d, d};
+    L.cv = LinearW{kvw + (size_t)d * d, kvb + d, nullptr, nullptr, d, d};
+    NEED(nm("cross.out.w"), &L.cout.w); NEED(nm("cross.out.b"), &L.cout.b); L.cout.N = d; L.cout.K = d;
+    NEED(nm("ln3.g"), &L.ln3.g); NEED(nm("ln3.b"), &L.ln3.b);
+    NEED(nm("ffn1.w"), &L.ffn1.w); NEED(nm("ffn1.b"), &L.ffn1.b); L.ffn1.N = 4 * d; L.ffn1.K = d;
+    NEED(nm("ffn2.w"), &L.ffn2.w); NEED(nm("ffn2.b"), &L.ffn2.b); L.ffn2.N = d; L.ffn2.K = 4 * d;
+  }
+  NEED("dec.ln.g", &m->dec_ln.g); NEED("dec.ln.b", &m->dec_ln.b);
+#undef NEED
+  return FW_OK;
+}
+
+static int alloc_workspaces(Model* m) {
+  const fw_config& c = m->cfg;
+  const size_t B = m->max_batch, d = c.d_model, T = c.n_audio_ctx;
+  m->t_pad = ((c.n_audio_ctx + 63) / 64) * 64;  // 1536
+  int rc;
+#define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
+  A(m->ws_offsets, B + 1);
+  A(m->ws_chunk_max, B);
+  A(m->ws_nframes, B);
+  m->ws_raw_cap = (int64_t)B * c.n_mels * 3008;
+  A(m->ws_raw, (size_t)m->ws_raw_cap);
+  A(m->ws_feat32, B * c.n_mels * 3000);
+  A(m->ws_mel_cl, B * 3002 * m->c_pad);
+  A(m->ws_conv1, B * 3002 * d);
+  A(m->ws_x, B * T * d);
+  A(m->ws_x2, B * T * d);
+  A(m->ws_xn, B * T * d);
+  A(m->ws_qk, B * T * 2 * d);
+  A(m->ws_vt, B * d * m->t_pad);
+  A(m->ws_att, B * T * d);
+  A(m->ws_ffn, B * T * 4 * d);
+#undef A
+  // conv padding rows / V^T time padding must be zero and are never written again
+  FW_HIP(hipMemset(m->ws_conv1, 0, B * 3002 * d * sizeof(half_t)));
+  FW_HIP(hipMemset(m->ws_vt, 0, B * d * m->t_pad * sizeof(half_t)));
+  FW_HIP(hipMemset(m->ws_mel_cl, 0, B * 3002 * m->c_pad * sizeof(half_t)));
+  return FW_OK;
+}
+
+static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned, int device, int max_batch,
+                           int max_beam, fw_model** out) {
+  FW_CHECK_ARG(max_batch >= 1 && max_batch <= 256, "max_batch must be in [1,256], got %d", max_batch);
+  FW_CHECK_ARG(max_beam >= 1 && max_beam <= 16, "max_beam must be in [1,16], got %d", max_beam);
+  FW_CHECK_ARG(blob_bytes >= (int64_t)sizeof(BlobHeader), "weight blob too small");
+  BlobHeader h;
+  FW_HIP(hipMemcpy(&h, blob_dev, sizeof(h), hipMemcpyDeviceToHost));
+  FW_CHECK_ARG(memcmp(h.magic, FW_BLOB_MAGIC, 8) == 0 && h.version == 1, "bad weight blob magic/version");
+  FW_CHECK_ARG(h.total_bytes <= blob_bytes, "weight blob truncated (%lld > %lld)", (long long)h.total_bytes,
+               (long long)blob_bytes);
+  int rc = check_config(&h.cfg);
+  if (rc) return rc;
+  FW_CHECK_ARG(h.compute_type == FW_COMPUTE_FLOAT16 || h.compute_type == FW_COMPUTE_INT8_FLOAT16,
+               "unsupported compute type %d", h.compute_type);
+  std::vector<BlobEntry> entries(h.n_tensors);
+  FW_HIP(hipMemcpy(entries.data(), reinterpret_cast<const char*>(blob_dev) + sizeof(h),
+                   entries.size() * sizeof(BlobEntry), hipMemcpyDeviceToHost));
+  fw_model* fm = new fw_model();
+  Model* m = &fm->impl;
+  m->cfg = h.cfg;
+  m->compute_type = h.compute_type;
+  m->device = device;
+  m->max_batch = max_batch;
+  m->max_beam = max_beam;
+  m->blob = const_cast<void*>(blob_dev);
+  m->blob_owned = owned;
+  m->blob_bytes = blob_bytes;
+  for (auto& e : entries) {
+    DevTensor t;
+    t.ptr = reinterpret_cast<char*>(m->blob) + e.offset;
+    t.dtype = e.dtype;
+    t.ndim = e.ndim;
+    for (int k = 0; k < 4; ++k) t.dims[k] = e.dims[k];
+    m->tensors[e.name] = t;
+  }
+  auto fail = [&](int code) { fw_model_free(fm); return code; };
+  hipError_t he = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (he != hipSuccess) {
+    set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
+    return fail(FW_ENODEV);
+  }
+  if ((rc = bind_weights(m))) return fail(rc);
+  if ((rc = setup_logmel_consts(m))) return fail(rc);
+  if ((rc = alloc_workspaces(m))) return fail(rc);
+  if ((rc = gen_workspace_create(m))) return fail(rc);
+  he = hipDeviceSynchronize();
+  if (he != hipSuccess) {
+    set_error("device sync after model setup failed: %s", hipGetErrorString(he));
+    return fail(FW_ENODEV);
+  }
+  *out = fm;
+  return FW_OK;
+}
+
+// ---------------------------------------------------------------- layers
+int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t a_bs, half_t* C, int64_t ldc,
+               int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans) {
+  fwk::GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.a_bstride = a_bs;
+  p.W = L.w; p.ldw = L.K;
+  p.bias = L.b;
+  p.res = res; p.ldr = ldr; p.r_bstride = r_bs;
+  p.C = C; p.ldc = ldc; p.c_bstride = c_bs;
+  p.M = M; p.N = L.N; p.K = L.K;
+  p.act = act;
+  if (fwk::launch_gemm(m->stream, p, batch, trans) != 0) {
+    set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%lld", M, L.N, L.K, (long long)lda);
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+int run_encoder(Model* m, int B, half_t* out) {
+  const fw_config& c = m->cfg;
+  const int d = c.d_model, T = c.n_audio_ctx, H = c.n_heads;
+  const int64_t xs = (int64_t)T * d;
+  int rc;
+  {
+    // conv1: k=3, s=1 over the channel-last mel image; GELU; output rows 1..3000 of the padded conv1 image
+    ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * 3000.0 * d * (3.0 * c.n_mels), 0);
+    if ((rc = run_linear(m, m->conv1, m->ws_mel_cl, m->c_pad, (int64_t)3002 * m->c_pad, m->ws_conv1 + d, d,
+                         (int64_t)3002 * d, nullptr, 0, 0, 3000, B, 1, false)))
+      return rc;
+  }
+  {
+    // conv2: k=3, s=2: row t reads padded rows 2t..2t+2 (lda = 2d, K = 3d); GELU; + positional embedding
+    ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * (double)T * d * (3.0 * d), 0);
+    if ((rc = run_linear(m, m->conv2, m->ws_conv1, 2 * d, (int64_t)3002 * d, m->ws_x, d, xs, m->enc_pos, d, 0, T, B,
+                         1, false)))
+      return rc;
+  }
+  half_t* x = m->ws_x;
+  half_t* x2 = m->ws_x2;
+  for (int l = 0; l < c.n_enc_layers; ++l) {
+    const EncLayerW& L = m->enc[l];
+    {
+      ProfScope ps(m, PF_ENC_LN, 0, 4.0 * B * T * d);
+      fwk::launch_layernorm(m->stream, x, L.ln1.g, L.ln1.b, m->ws_xn, B * T, d);
+    }
+    {
+      ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * (double)T * d * (3.0 * d), 0);
+      if ((rc = run_linear(m, L.qk, m->ws_xn, d, xs, m->ws_qk, 2 * d, (int64_t)T * 2 * d, nullptr, 0, 0, T, B, 0,
+                           false)))
+        return rc;
+      if ((rc = run_linear(m, L.v, m->ws_xn, d, xs, m->ws_vt, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
+                           true)))
+        return rc;
+    }
+    {
+      ProfScope ps(m, PF_ENC_ATTN, 4.0 * B * (double)T * T * d, 0);
+      fwk::launch_attn_enc(m->stream, m->ws_qk, m->ws_qk + d, 2 * d, (int64_t)T * 2 * d, m->ws_vt, m->t_pad,
+                           (int64_t)d * m->t_pad, m->ws_att, d, xs, B, H, T);
+    }
+    {
+      ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * (double)T * d * d, 0);
+      if ((rc = run_linear(m, L.out, m->ws_att, d, xs, x2, d, xs, x, d, xs, T, B, 0, false))) return rc;
+    }
+    {
+      ProfScope ps(m, PF_ENC_LN, 0, 4.0 * B * T * d);
+      fwk::launch_layernorm(m->stream, x2, L.ln2.g, L.ln2.b, m->ws_xn, B * T, d);
+    }
+    {
+      ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * (double)T * d * (8.0 * d), 0);
+      if ((rc = run_linear(m, L.ffn1, m->ws_xn, d, xs, m->ws_ffn, 4 * d, (int64_t)T * 4 * d, nullptr, 0, 0, T, B, 1,
+                           false)))
+        return rc;
+      if ((rc = run_linear(m, L.ffn2, m->ws_ffn, 4 * d, (int64_t)T * 4 * d, x, d, xs, x2, d, xs, T, B, 0, false)))
+        return rc;
+    }
+  }
+  {
+    ProfScope ps(m, PF_ENC_LN, 0, 4.0 * B * T * d);
+    fwk::launch_layernorm(m->stream, x, m->enc_ln_post.g, m->enc_ln_post.b, out, B * T, d);
+  }
+  hipError_t he = hipGetLastError();
+  if (he != hipSuccess) {
+    set_error("encoder launch failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+static int new_tensor(Model* m, int B, fw_tensor** out) {
+  fw_tensor* t = new fw_tensor();
+  t->impl.owner = m;
+  t->impl.B = B;
+  t->impl.T = m->cfg.n_audio_ctx;
+  t->impl.D = m->cfg.d_model;
+  t->impl.id = next_tensor_id();
+  int rc = dev_alloc_t(&t->impl.data, (size_t)B * t->impl.T * t->impl.D);
+  if (rc) {
+    delete t;
+    return rc;
+  }
+  *out = t;
+  return FW_OK;
+}
+
+static int ensure_pcm(Model* m, int64_t n) {
+  if (n <= m->ws_pcm_cap) return FW_OK;
+  if (m->ws_pcm) (void)hipFree(m->ws_pcm);
+  m->ws_pcm = nullptr;
+  m->ws_pcm_cap = 0;
+  int rc = dev_alloc_t(&m->ws_pcm, (size_t)n);
+  if (rc) return rc;
+  m->ws_pcm_cap = n;
+  return FW_OK;
+}
+
+static int check_offsets(const int64_t* offsets, int B, int64_t* total, int* max_frames) {
+  FW_CHECK_ARG(offsets && offsets[0] == 0, "offsets[0] must be 0");
+  int mf = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = offsets[b + 1] - offsets[b];
+    FW_CHECK_ARG(n >= 0 && n < (int64_t)1 << 30, "chunk %d has invalid length %lld", b, (long long)n);
+    mf = std::max(mf, (int)((n + 160) / 160));
+  }
+  *total = offsets[B];
+  *max_frames = mf;
+  return FW_OK;
+}
+
+// raw buffer able to hold [B][n_mels][stride]
+static int ensure_raw(Model* m, int B, int stride) {
+  const int64_t need = (int64_t)B * m->cfg.n_mels * stride;
+  if (need <= m->ws_raw_cap) return FW_OK;
+  (void)hipFree(m->ws_raw);
+  m->ws_raw = nullptr;
+  m->ws_raw_cap = 0;
+  int rc = dev_alloc_t(&m->ws_raw, (size_t)need);
+  if (rc) return rc;
+  m->ws_raw_cap = need;
+  return FW_OK;
+}
+
+// log-mel for B ragged chunks whose PCM already sits at pcm_dev; writes ws_feat32 and/or ws_mel_cl
+static int logmel_batch(Model* m, const float* pcm_dev, const int64_t* offsets_host, int B, bool want_f32,
+                        bool want_cl) {
+  int64_t total;
+  int max_frames;
+  int rc = check_offsets(offsets_host, B, &total, &max_frames);
+  if (rc) return rc;
+  const int stride = std::max(3008, (max_frames + 7) / 8 * 8);
+  if ((rc = ensure_raw(m, B, stride))) return rc;
+  FW_HIP(hipMemcpyAsync(m->ws_offsets, offsets_host, (B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
+  {
+    ProfScope ps(m, PF_LOGMEL, 0, (double)total * 4 + (double)B * m->cfg.n_mels * 3000 * (want_f32 ? 4 : 2));
+    fwk::launch_logmel(m->stream, pcm_dev, m->ws_offsets, B, max_frames, m->lm_consts, m->lm_filtT, m->lm_mel_pad,
+                       m->cfg.n_mels, m->ws_raw, (int64_t)m->cfg.n_mels * stride, stride, m->ws_chunk_max, 1, 3000,
+                       want_f32 ? m->ws_feat32 : nullptr, want_cl ? m->ws_mel_cl : nullptr, m->c_pad, m->ws_nframes);
+  }
+  hipError_t he = hipGetLastError();
+  if (he != hipSuccess) {
+    set_error("logmel launch failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+}  // namespace fw
+
+using namespace fw;
+
+// ================================================================== C ABI
+extern "C" {
+
+const char* fw_last_error(void) { return g_err; }
+int32_t fw_abi_version(void) { return FW_ABI_VERSION; }
+
+int32_t fw_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t fw_model_create(const fw_config* cfg, const fw_weight* weights, int32_t n_weights, int32_t compute_type,
+                        int32_t device_index, int32_t max_batch, int32_t max_beam, fw_model** out) {
+  FW_CHECK_ARG(cfg && weights && out, "null argument");
+  FW_CHECK_ARG(compute_type == FW_COMPUTE_FLOAT16 || compute_type == FW_COMPUTE_INT8_FLOAT16,
+               "unsupported compute_type %d", compute_type);
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  const int ndev = fw_device_count();
+  if (ndev <= 0) {
+    set_error("no HIP device visible: libfwamd has no CPU fallback");
+    return FW_ENODEV;
+  }
+  FW_CHECK_ARG(device_index >= 0 && device_index < ndev, "device_index %d out of range (%d devices)", device_index,
+               ndev);
+  FW_HIP(hipSetDevice(device_index));
+  std::vector<uint8_t> blob;
+  if ((rc = pack_blob(cfg, weights, n_weights, compute_type, blob))) return rc;
+  void* dblob = nullptr;
+  if ((rc = dev_alloc(&dblob, blob.size()))) return rc;
+  hipError_t he = hipMemcpy(dblob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    (void)hipFree(dblob);
+    set_error("weight upload failed: %s", hipGetErrorString(he));
+    return FW_ENODEV;
+  }
+  rc = model_from_blob(dblob, (int64_t)blob.size(), true, device_index, max_batch, max_beam, out);
+  return rc;
+}
+
+int32_t fw_pack_blob_size(const fw_config* cfg, const fw_weight* weights, int32_t n_weights, int32_t compute_type,
+                          int64_t* size_out, void** handle_out) {
+  FW_CHECK_ARG(cfg && weights && size_out && handle_out, "null argument");
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  auto* blob = new std::vector<uint8_t>();
+  if ((rc = pack_blob(cfg, weights, n_weights, compute_type, *blob))) {
+    delete blob;
+    return rc;
+  }
+  *size_out = (int64_t)blob->size();
+  *handle_out = blob;
+  return FW_OK;
+}
+int32_t fw_pack_blob_copy(void* handle, void* dst, int64_t dst_bytes) {
+  auto* blob = reinterpret_cast<std::vector<uint8_t>*>(handle);
+  FW_CHECK_ARG(blob && dst && dst_bytes >= (int64_t)blob->size(), "bad blob copy arguments");
+  memcpy(dst, blob->data(), blob->size());
+  return FW_OK;
+}
+void fw_pack_blob_free(void* handle) { delete reinterpret_cast<std::vector<uint8_t>*>(handle); }
+
+int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev, int64_t blob_bytes,
+                                      int32_t compute_type, int32_t device_index, int32_t max_batch,
+                                      int32_t max_beam, fw_model** out) {
+  (void)cfg;
+  (void)compute_type;
+  FW_CHECK_ARG(blob_dev && out, "null argument");
+  const int ndev = fw_device_count();
+  if (ndev <= 0) {
+    set_error("no HIP device visible: libfwamd has no CPU fallback");
+    return FW_ENODEV;
+  }
+  FW_CHECK_ARG(device_index >= 0 && device_index < ndev, "device_index %d out of range", device_index);
+  FW_HIP(hipSetDevice(device_index));
+  return model_from_blob(blob_dev, blob_bytes, false, device_index, max_batch, max_beam, out);
+}
+
+void fw_model_free(fw_model* fm) {
+  if (!fm) return;
+  Model* m = &fm->impl;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  gen_workspace_free(m);
+  void* ptrs[] = {m->lm_consts, m->lm_filtT, m->ws_pcm, m->ws_offsets, m->ws_raw, m->ws_chunk_max, m->ws_nframes,
+                  m->ws_feat32, m->ws_mel_cl, m->ws_conv1, m->ws_x, m->ws_x2, m->ws_xn, m->ws_qk, m->ws_vt,
+                  m->ws_att, m->ws_ffn};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (m->blob && m->blob_owned) (void)hipFree(m->blob);
+  for (auto& p : m->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete fm;
+}
+
+int32_t fw_model_info(const fw_model* fm, fw_config* cfg_out, int32_t* compute_type, int32_t* device_index,
+                      int32_t* max_batch, int32_t* max_beam) {
+  FW_CHECK_ARG(fm, "null model");
+  const Model* m = &fm->impl;
+  if (cfg_out) *cfg_out = m->cfg;
+  if (compute_type) *compute_type = m->compute_type;
+  if (device_index) *device_index = m->device;
+  if (max_batch) *max_batch = m->max_batch;
+  if (max_beam) *max_beam = m->max_beam;
+  return FW_OK;
+}
+
+int32_t fw_logmel(fw_model* fm, const float* pcm, const int64_t* offsets, int32_t B, float* out,
+                  int32_t* n_frames_out) {
+  FW_CHECK_ARG(fm && offsets && out, "null argument");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  int64_t total; int mf;
+  int rc = check_offsets(offsets, B, &total, &mf);
+  if (rc) return rc;
+  FW_CHECK_ARG(total == 0 || pcm, "null pcm");
+  if ((rc = ensure_pcm(m, std::max<int64_t>(total, 1)))) return rc;
+  if (total) FW_HIP(hipMemcpyAsync(m->ws_pcm, pcm, total * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  if ((rc = logmel_batch(m, m->ws_pcm, offsets, B, true, false))) return rc;
+  FW_HIP(hipMemcpyAsync(out, m->ws_feat32, (size_t)B * m->cfg.n_mels * 3000 * sizeof(float), hipMemcpyDeviceToHost,
+                        m->stream));
+  if (n_frames_out)
+    FW_HIP(hipMemcpyAsync(n_frames_out, m->ws_nframes, B * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  FW_HIP(hipStreamSynchronize(m->stream));
+  return FW_OK;
+}
+
+int32_t fw_logmel_full(fw_model* fm, const float* pcm, int64_t n_samples, float* out, int64_t out_frames) {
+  FW_CHECK_ARG(fm && out, "null argument");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(n_samples >= 0 && n_samples < (int64_t)1 << 30, "invalid n_samples");
+  const int64_t nf = (n_samples + 160) / 160;
+  FW_CHECK_ARG(out_frames == nf, "out_frames must be n_samples/160 + 1 = %lld, got %lld", (long long)nf,
+               (long long)out_frames);
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  int rc;
+  if ((rc = ensure_pcm(m, std::max<int64_t>(n_samples, 1)))) return rc;
+  if (n_samples) FW_HIP(hipMemcpyAsync(m->ws_pcm, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  const int stride = (int)((nf + 7) / 8 * 8);
+  if ((rc = ensure_raw(m, 1, std::max(stride, 3008)))) return rc;
+  const int rstride = std::max(stride, 3008);
+  int64_t offs[2] = {0, n_samples};
+  FW_HIP(hipMemcpyAsync(m->ws_offsets, offs, 2 * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
+  float* dout = nullptr;
+  if ((rc = dev_alloc_t(&dout, (size_t)m->cfg.n_mels * nf))) return rc;
+  {
+    ProfScope ps(m, PF_LOGMEL, 0, (double)n_samples * 4 + (double)m->cfg.n_mels * nf * 4);
+    fwk::launch_logmel(m->stream, m->ws_pcm, m->ws_offsets, 1, (int)nf, m->lm_consts, m->lm_filtT, m->lm_mel_pad,
+                       m->cfg.n_mels, m->ws_raw, (int64_t)m->cfg.n_mels * rstride, rstride, m->ws_chunk_max, 0,
+                       (int)nf, dout, nullptr, m->c_pad, nullptr);
+  }
+  hipError_t he = hipMemcpyAsync(out, dout, (size_t)m->cfg.n_mels * nf * sizeof(float), hipMemcpyDeviceToHost,
+                                 m->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(m->stream);
+  (void)hipFree(dout);
+  if (he != hipSuccess) {
+    set_error("logmel_full failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+int32_t fw_encode(fw_model* fm, const float* features, int32_t B, fw_tensor** out) {
+  FW_CHECK_ARG(fm && features && out, "null argument");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  FW_HIP(hipMemcpyAsync(m->ws_feat32, features, (size_t)B * m->cfg.n_mels * 3000 * sizeof(float),
+                        hipMemcpyHostToDevice, m->stream));
+  fwk::launch_features_to_cl(m->stream, m->ws_feat32, B, m->cfg.n_mels, 3000, m->ws_mel_cl, m->c_pad);
+  fw_tensor* t = nullptr;
+  int rc = new_tensor(m, B, &t);
+  if (rc) return rc;
+  if ((rc = run_encoder(m, B, t->impl.data))) {
+    fw_tensor_free(t);
+    return rc;
+  }
+  hipError_t he = hipStreamSynchronize(m->stream);
+  if (he != hipSuccess) {
+    fw_tensor_free(t);
+    set_error("encode failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  prof_collect(m);
+  *out = t;
+  return FW_OK;
+}
+
+static int encode_pcm_common(Model* m, const float* pcm_dev, const int64_t* offsets, int B, fw_tensor** out) {
+  int rc;
+  if ((rc = logmel_batch(m, pcm_dev, offsets, B, false, true))) return rc;
+  fw_tensor* t = nullptr;
+  if ((rc = new_tensor(m, B, &t))) return rc;
+  if ((rc = run_encoder(m, B, t->impl.data))) {
+    fw_tensor_free(t);
+    return rc;
+  }
+  hipError_t he = hipStreamSynchronize(m->stream);
+  if (he != hipSuccess) {
+    fw_tensor_free(t);
+    set_error("encode_pcm failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  prof_collect(m);
+  *out = t;
+  return FW_OK;
+}
+
+int32_t fw_encode_pcm(fw_model* fm, const float* pcm, const int64_t* offsets, int32_t B, fw_tensor** out) {
+  FW_CHECK_ARG(fm && offsets && out, "null argument");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  int64_t total; int mf;
+  int rc = check_offsets(offsets, B, &total, &mf);
+  if (rc) return rc;
+  FW_CHECK_ARG(total == 0 || pcm, "null pcm");
+  if ((rc = ensure_pcm(m, std::max<int64_t>(total, 1)))) return rc;
+  if (total) FW_HIP(hipMemcpyAsync(m->ws_pcm, pcm, total * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  return encode_pcm_common(m, m->ws_pcm, offsets, B, out);
+}
+
+int32_t fw_encode_pcm_dev(fw_model* fm, const float* pcm_dev, const int64_t* offsets, int32_t B, fw_tensor** out) {
+  FW_CHECK_ARG(fm && pcm_dev && offsets && out, "null argument");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  return encode_pcm_common(m, pcm_dev, offsets, B, out);
+}
+
+int32_t fw_tensor_shape(const fw_tensor* t, int32_t* B, int32_t* T, int32_t* D) {
+  FW_CHECK_ARG(t, "null tensor");
+  if (B) *B = t->impl.B;
+  if (T) *T = t->impl.T;
+  if (D) *D = t->impl.D;
+  return FW_OK;
+}
+
+int32_t fw_tensor_to_host(fw_model* fm, const fw_tensor* t, float* out) {
+  FW_CHECK_ARG(fm && t && out, "null argument");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  const size_t n = (size_t)t->impl.B * t->impl.T * t->impl.D;
+  float* tmp = nullptr;
+  int rc = dev_alloc_t(&tmp, n);
+  if (rc) return rc;
+  fwk::launch_f16_to_f32(m->stream, t->impl.data, tmp, (int64_t)n);
+  hipError_t he = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, m->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(m->stream);
+  (void)hipFree(tmp);
+  if (he != hipSuccess) {
+    set_error("tensor_to_host failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+int32_t fw_tensor_from_host(fw_model* fm, const float* data, int32_t B, fw_tensor** out) {
+  FW_CHECK_ARG(fm && data && out, "null argument");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  fw_tensor* t = nullptr;
+  int rc = new_tensor(m, B, &t);
+  if (rc) return rc;
+  const size_t n = (size_t)B * t->impl.T * t->impl.D;
+  float* tmp = nullptr;
+  if ((rc = dev_alloc_t(&tmp, n))) { fw_tensor_free(t); return rc; }
+  hipError_t he = hipMemcpyAsync(tmp, data, n * sizeof(float), hipMemcpyHostToDevice, m->stream);
+  fwk::launch_f32_to_f16(m->stream, tmp, t->impl.data, (int64_t)n);
+  if (he == hipSuccess) he = hipStreamSynchronize(m->stream);
+  (void)hipFree(tmp);
+  if (he != hipSuccess) {
+    fw_tensor_free(t);
+    set_error("tensor_from_host failed: %s", hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  *out = t;
+  return FW_OK;
+}
+
+void fw_tensor_free(fw_tensor* t) {
+  if (!t) return;
+  if (t->impl.owner) (void)hipSetDevice(t->impl.owner->device);
+  if (t->impl.data) (void)hipFree(t->impl.data);
+  delete t;
+}
+
+// ---------------------------------------------------------------- measurement hooks
+void fw_prof_enable(fw_model* fm, int32_t on) { if (fm) fm->impl.prof_on = on != 0; }
+void fw_prof_reset(fw_model* fm) {
+  if (!fm) return;
+  prof_collect(&fm->impl);
+  for (auto& p : fm->impl.prof) p = ProfAcc();
+}
+int32_t fw_prof_count(void) { return PF_COUNT; }
+const char* fw_prof_name(int32_t i) { return (i >= 0 && i < PF_COUNT) ? kProfNames[i] : ""; }
+int32_t fw_prof_get(fw_model* fm, int32_t i, double* ms, int64_t* launches, double* flops, double* bytes) {
+  FW_CHECK_ARG(fm && i >= 0 && i < PF_COUNT, "bad profile index");
+  prof_collect(&fm->impl);
+  const ProfAcc& p = fm->impl.prof[i];
+  if (ms) *ms = p.ms;
+  if (launches) *launches = p.launches;
+  if (flops) *flops = p.flops;
+  if (bytes) *bytes = p.bytes;
+  return FW_OK;
+}
+int32_t fw_synchronize(fw_model* fm) {
+  FW_CHECK_ARG(fm, "null model");
+  FW_HIP(hipSetDevice(fm->impl.device));
+  FW_HIP(hipStreamSynchronize(fm->impl.stream));
+  return FW_OK;
+}
+int32_t fw_dev_alloc(fw_model* fm, int64_t bytes, void** out_dev) {
+  FW_CHECK_ARG(fm && out_dev && bytes >= 0, "bad argument");
+  FW_HIP(hipSetDevice(fm->impl.device));
+  return dev_alloc(out_dev, (size_t)bytes);
+}
+int32_t fw_dev_free(fw_model* fm, void* dev) {
+  FW_CHECK_ARG(fm, "null model");
+  FW_HIP(hipSetDevice(fm->impl.device));
+  if (dev) FW_HIP(hipFree(dev));
+  return FW_OK;
+}
+int32_t fw_dev_upload(fw_model* fm, void* dst_dev, const void* src_host, int64_t bytes) {
+  FW_CHECK_ARG(fm && dst_dev && src_host && bytes >= 0, "bad argument");
+  FW_HIP(hipSetDevice(fm->impl.device));
+  FW_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+  return FW_OK;
+}
+
+// ---------------------------------------------------------------- kernel test hooks
+static int upload_f16(Model* m, const float* src, size_t n, half_t** dst) {
+  int rc = dev_alloc_t(dst, n);
+  if (rc) return rc;
+  std::vector<uint16_t> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_f16_bits(src[i]);
+  FW_HIP(hipMemcpy(*dst, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return FW_OK;
+}
+static int download_f16(Model* m, const half_t* src, size_t n, float* dst) {
+  std::vector<uint16_t> tmp(n);
+  FW_HIP(hipStreamSynchronize(m->stream));
+  FW_HIP(hipMemcpy(tmp.data(), src, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    half_t h;
+    memcpy(&h, &tmp[i], 2);
+    dst[i] = (float)h;
+  }
+  return FW_OK;
+}
+
+int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* bias, const float* residual,
+                     int32_t M, int32_t N, int32_t K, int32_t act_gelu, int32_t use_int8, float* out) {
+  FW_CHECK_ARG(fm && A && W && out, "null argument");
+  FW_CHECK_ARG(use_int8 == 0, "int8 test path not built yet");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  half_t *dA = nullptr, *dW = nullptr, *dB = nullptr, *dR = nullptr, *dC = nullptr;
+  int rc;
+  if ((rc = upload_f16(m, A, (size_t)M * K, &dA))) return rc;
+  if ((rc = upload_f16(m, W, (size_t)N * K, &dW))) return rc;
+  if (bias && (rc = upload_f16(m, bias, N, &dB))) return rc;
+  if (residual && (rc = upload_f16(m, residual, (size_t)M * N, &dR))) return rc;
+  if ((rc = dev_alloc_t(&dC, (size_t)M * N))) return rc;
+  LinearW L{dW, dB, nullptr, nullptr, N, K};
+  if (act_gelu >= 2) {
+    // transposed-output mode: out is [N][M]
+    rc = run_linear(m, L, dA, K, 0, dC, M, 0, nullptr, 0, 0, M, 1, act_gelu - 2, true);
+  } else {
+    rc = run_linear(m, L, dA, K, 0, dC, N, 0, dR, N, 0, M, 1, act_gelu, false);
+  }
+  if (!rc) rc = download_f16(m, dC, (size_t)M * N, out);
+  for (half_t* p : {dA, dW, dB, dR, dC})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+int32_t fw_test_layernorm(fw_model* fm, const float* x, const float* g, const float* b, int32_t rows, int32_t d,
+                          float* out) {
+  FW_CHECK_ARG(fm && x && g && b && out, "null argument");
+  FW_CHECK_ARG(d % 128 == 0 && d <= 1280, "d must be a multiple of 128 and <= 1280");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  half_t *dx = nullptr, *dg = nullptr, *db = nullptr, *dy = nullptr;
+  int rc;
+  if ((rc = upload_f16(m, x, (size_t)rows * d, &dx))) return rc;
+  if ((rc = upload_f16(m, g, d, &dg))) return rc;
+  if ((rc = upload_f16(m, b, d, &db))) return rc;
+  if ((rc = dev_alloc_t(&dy, (size_t)rows * d))) return rc;
+  fwk::launch_layernorm(m->stream, dx, dg, db, dy, rows, d);
+  rc = download_f16(m, dy, (size_t)rows * d, out);
+  for (half_t* p : {dx, dg, db, dy})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+// q,k,v,out: float32 [B][T][H*64]
+int32_t fw_test_attention(fw_model* fm, const float* q, const float* k, const float* v, int32_t B, int32_t H,
+                          int32_t T, float* out) {
+  FW_CHECK_ARG(fm && q && k && v && out, "null argument");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  const int d = H * 64, tp = (T + 63) / 64 * 64;
+  const size_t n = (size_t)B * T * d;
+  half_t *dq = nullptr, *dk = nullptr, *dvt = nullptr, *dout = nullptr;
+  int rc;
+  if ((rc = upload_f16(m, q, n, &dq))) return rc;
+  if ((rc = upload_f16(m, k, n, &dk))) return rc;
+  std::vector<float> vt((size_t)B * d * tp, 0.f);
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t)
+      for (int c = 0; c < d; ++c) vt[((size_t)b * d + c) * tp + t] = v[((size_t)b * T + t) * d + c];
+  if ((rc = upload_f16(m, vt.data(), vt.size(), &dvt))) return rc;
+  if ((rc = dev_alloc_t(&dout, n))) return rc;
+  fwk::launch_attn_enc(m->stream, dq, dk, d, (int64_t)T * d, dvt, tp, (int64_t)d * tp, dout, d, (int64_t)T * d, B, H,
+                       T);
+  rc = download_f16(m, dout, n, out);
+  for (half_t* p : {dq, dk, dvt, dout})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+}  // extern "C"

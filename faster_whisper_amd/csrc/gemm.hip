@@ -1,0 +1,239 @@
+// K2/K3/K6/K8-K11 — the dense fp16 MFMA GEMM of the encoder (and of every
+// "many rows" linear: conv1d-as-GEMM, fused QKV, out-proj, FFN, cross-K/V projection).
+//
+//   C[z][m][n] = epi( sum_k A[z][m][k] * W[n][k] )      A, W, C fp16; fp32 accumulate
+//   epi(v)     = act(v + bias[n]) + res[z][m][n]         act = identity | exact-erf GELU
+//
+// Both operands are K-contiguous ("B^T" form), which is the natural MFMA fragment
+// order: lane (row = l&31, k-octet = l>>5) reads 16 contiguous bytes.
+//
+// gfx950 mapping
+//  * 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
+//    v_mfma_f32_32x32x16_f16 (64 accumulator VGPRs).
+//  * global -> VGPR (16 B/lane, coalesced 128 B rows) -> LDS (ds_write_b128) ->
+//    MFMA fragments (ds_read_b128). LDS rows are 128 B; the 16-byte chunk index is
+//    XOR-swizzled with (row>>1)&7, which makes every ds_read_b128 lane group
+//    conflict-free (MI355X_MICROARCH.md LDS table).
+//  * double-buffered LDS, ONE barrier per K tile; the next tile's global loads are
+//    issued before the MFMA block and written to LDS after it (issue-early /
+//    write-late), so HBM/L2 latency hides under the matrix pipe.
+//  * normal mode computes D = W_tile * A_tile^T so that each lane ends up with four
+//    consecutive n of one row m -> 8-byte stores; TRANS mode computes D = A_tile *
+//    W_tile^T, each lane holds four consecutive m of one column n, and the tile is
+//    stored transposed (Ct[z][n][m]) — used to emit V^T for the attention kernels
+//    without a separate transpose pass.
+//  * conv1d (k=3, stride s) over a channel-last, zero-padded image is this GEMM with
+//    lda = s*C and K = 3*C: the three taps of an output row are contiguous in memory.
+//  * 1-D grid with a bijective XCD remap; n fastest inside an m panel so the blocks
+//    resident on one XCD share the A panel and the whole W in that XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+#define GB_M 128
+#define GB_N 128
+#define GB_K 64
+#define GB_TILE_HALVES (128 * 64)
+
+template <bool TRANS>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  half_t* sA = reinterpret_cast<half_t*>(smem_raw);     // [2][128][64]
+  half_t* sW = sA + 2 * GB_TILE_HALVES;                 // [2][128][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int per_z = p.nMt * p.nNt;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = bid / per_z;
+  bid -= z * per_z;
+  const int mt = bid / p.nNt, nt = bid - mt * p.nNt;
+  const int m0 = mt * GB_M, n0 = nt * GB_N;
+
+  const half_t* Ab = p.A + (size_t)z * p.a_bstride;
+  // staging map: thread -> (row r0 + 32*i, 16-byte chunk c) of the [128][64] tile
+  const int c = tid & 7, r0 = tid >> 3;
+  const half_t* gA[4];
+  const half_t* gW[4];
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + 32 * i;
+    int am = m0 + row; if (am > p.M - 1) am = p.M - 1;
+    int wn_ = n0 + row; if (wn_ > p.N - 1) wn_ = p.N - 1;
+    gA[i] = Ab + (size_t)am * p.lda + c * 8;
+    gW[i] = p.W + (size_t)wn_ * p.ldw + c * 8;
+    soff[i] = row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
+  }
+  intx4 ra[4], rw[4];
+  const int nk = p.K / GB_K;
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const intx4*>(gA[i]);
+    rw[i] = *reinterpret_cast<const intx4*>(gW[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<intx4*>(sA + soff[i]) = ra[i];
+    *reinterpret_cast<intx4*>(sW + soff[i]) = rw[i];
+  }
+  __syncthreads();
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = floatx16{0};
+
+  // fragment row bases (in halves) and their swizzle keys
+  int arow[2], wrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    arow[i] = wm * 64 + i * 32 + l31;
+    wrow[i] = wn * 64 + i * 32 + l31;
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      const int koff = (kt + 1) * GB_K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const intx4*>(gA[i] + koff);
+        rw[i] = *reinterpret_cast<const intx4*>(gW[i] + koff);
+      }
+    }
+    const half_t* cA = sA + cur * GB_TILE_HALVES;
+    const half_t* cW = sW + cur * GB_TILE_HALVES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = ks * 2 + hi;
+      half8_t fa[2], fw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const half8_t*>(cA + arow[i] * 64 + ((chunk ^ ((arow[i] >> 1) & 7)) << 3));
+        fw[i] = *reinterpret_cast<const half8_t*>(cW + wrow[i] * 64 + ((chunk ^ ((wrow[i] >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (TRANS)  // D[m][n]: acc[mi][ni]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+          else        // D[n][m]: acc[ni][mi]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) {
+      half_t* nA = sA + (cur ^ 1) * GB_TILE_HALVES;
+      half_t* nW = sW + (cur ^ 1) * GB_TILE_HALVES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<intx4*>(nA + soff[i]) = ra[i];
+        *reinterpret_cast<intx4*>(nW + soff[i]) = rw[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------- epilogue ----------------------------------
+  if (!TRANS) {
+    half_t* Cb = p.C + (size_t)z * p.c_bstride;
+    const half_t* Rb = p.res ? p.res + (size_t)z * p.r_bstride : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
+          if (n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][g * 4 + e];
+          if (p.bias) {
+            const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+          }
+          if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          }
+          if (Rb) {
+            const half4_t rv = *reinterpret_cast<const half4_t*>(Rb + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          }
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+          *reinterpret_cast<half4_t*>(Cb + (size_t)m * p.ldc + n) = o;
+        }
+      }
+  } else {
+    half_t* Cb = p.C + (size_t)z * p.c_bstride;  // Ct[z][n][m], ldc = row stride of Ct
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? (float)p.bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int m = m0 + wm * 64 + mi * 32 + 8 * g + 4 * hi;
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[mi][ni][g * 4 + e] + bv;
+            if (p.act == 1) v = gelu_erf(v);
+            o[e] = (half_t)v;
+          }
+          half_t* dst = Cb + (size_t)n * p.ldc + m;
+          if (m + 3 < p.M) {
+            *reinterpret_cast<half4_t*>(dst) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (m + e < p.M) dst[e] = o[e];
+          }
+        }
+      }
+  }
+}
+
+namespace fwk {
+
+static bool g_gemm_attr_set = false;
+
+int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
+  GemmParams p = pin;
+  if (p.K % GB_K != 0 || p.K <= 0) return -1;
+  if ((p.lda % 8) || (p.ldw % 8) || (p.a_bstride % 8)) return -1;
+  if (!trans && ((p.N % 4) || (p.ldc % 4) || (p.c_bstride % 4))) return -1;
+  p.nMt = (p.M + GB_M - 1) / GB_M;
+  p.nNt = (p.N + GB_N - 1) / GB_N;
+  const int lds = 4 * GB_TILE_HALVES * (int)sizeof(half_t);  // 64 KiB
+  if (!g_gemm_attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    g_gemm_attr_set = true;
+  }
+  const int grid = p.nMt * p.nNt * batch;
+  if (trans)
+    gemm_f16_kernel<true><<<grid, 256, lds, st>>>(p);
+  else
+    gemm_f16_kernel<false><<<grid, 256, lds, st>>>(p);
+  return 0;
+}
+
+}  // namespace fwk

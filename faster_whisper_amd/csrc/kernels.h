@@ -1,0 +1,42 @@
+// Host-side launch API of the gfx950 kernels (internal to libfwamd.so).
+#pragma once
+#include "common.h"
+
+namespace fwk {
+
+// ---- log-mel (logmel.hip) ---------------------------------------------------------
+size_t logmel_lds_bytes();
+void launch_logmel(hipStream_t st, const float* pcm_dev, const int64_t* offsets_dev, int B, int max_frames_total,
+                   const float* consts, const float* filtT, int mel_pad, int n_mels, float* raw,
+                   int64_t raw_bstride, int raw_stride, int* chunk_max, int drop_last, int out_frames,
+                   float* out_f32, half_t* out_cl, int c_pad, int* n_frames_out);
+void launch_features_to_cl(hipStream_t st, const float* feats_dev, int B, int n_mels, int frames, half_t* out_cl,
+                           int c_pad);
+
+// ---- dense GEMM (gemm.hip) --------------------------------------------------------
+struct GemmParams {
+  const half_t* A; int64_t lda; int64_t a_bstride;   // A[z][m][k], k contiguous
+  const half_t* W; int64_t ldw;                       // W[n][k]
+  const half_t* bias;                                 // [N] or null
+  const half_t* res; int64_t ldr; int64_t r_bstride;  // residual [z][m][n] or null (added after act)
+  half_t* C; int64_t ldc; int64_t c_bstride;          // C[z][m][n]   (TRANS: Ct[z][n][m], ldc = row stride)
+  int M, N, K;
+  int act;                                            // 0 none, 1 exact GELU
+  int nMt, nNt;                                       // filled by launch_gemm
+};
+int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
+
+// ---- row kernels (rowops.hip) -----------------------------------------------------
+// y[r] = LN(x[r]) * g + b, eps 1e-5, fp32 statistics (two-pass in registers)
+void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d);
+void launch_f32_to_f16(hipStream_t st, const float* x, half_t* y, int64_t n);
+void launch_f16_to_f32(hipStream_t st, const half_t* x, float* y, int64_t n);
+
+// ---- encoder attention (attn_enc.hip) ---------------------------------------------
+// q,k: [B][T][ld] fp16 (head h at column h*64), vt: [B][H*64][ldvt] (V transposed, time contiguous)
+// out: [B][T][ldo]. softmax(q k^T / 8) v, non-causal, T keys.
+void launch_attn_enc(hipStream_t st, const half_t* q, const half_t* k, int64_t ld, int64_t qk_bstride,
+                     const half_t* vt, int64_t ldvt, int64_t vt_bstride, half_t* out, int64_t ldo,
+                     int64_t o_bstride, int B, int H, int T);
+
+}  // namespace fwk

@@ -1,0 +1,96 @@
+"""Weight naming + the deterministic synthetic weight generator.
+
+No Whisper checkpoint exists in the build environment, so parity
+tests and the benchmark use seeded random weights of the exact architecture.  The same
+dict (name -> numpy array) feeds the HIP engine (via fw_model_create) and the CPU oracle.
+
+Tensor names / shapes (PyTorch [out, in] convention, biases 1-D):
+  enc.conv1.w [d, n_mels, 3]  enc.conv1.b [d]   enc.conv2.w [d, d, 3]  enc.conv2.b [d]
+  enc.pos [1500, d]
+  enc.{i}.ln1.g/b  enc.{i}.attn.qkv.w [3d, d] (q rows, k rows, v rows)  enc.{i}.attn.qkv.b [3d] (k part = 0)
+  enc.{i}.attn.out.w [d, d] / .b   enc.{i}.ln2.g/b   enc.{i}.ffn1.w [4d, d] / .b   enc.{i}.ffn2.w [d, 4d] / .b
+  enc.ln_post.g/b
+  dec.tok_emb [V, d]  dec.pos [448, d]
+  dec.{i}.ln1.g/b  dec.{i}.self.qkv.w/.b  dec.{i}.self.out.w/.b
+  dec.{i}.ln2.g/b  dec.{i}.cross.q.w/.b  dec.{i}.cross.kv.w [2d, d] (k rows, v rows) / .b (k part = 0)
+  dec.{i}.cross.out.w/.b  dec.{i}.ln3.g/b  dec.{i}.ffn1.w/.b  dec.{i}.ffn2.w/.b
+  dec.ln.g/b
+"""
+import zlib
+from typing import Dict
+
+import numpy as np
+
+from .config import WhisperConfig
+
+
+def weight_shapes(cfg: WhisperConfig) -> Dict[str, tuple]:
+    d = cfg.d_model
+    s = {
+        "enc.conv1.w": (d, cfg.n_mels, 3), "enc.conv1.b": (d,),
+        "enc.conv2.w": (d, d, 3), "enc.conv2.b": (d,),
+        "enc.pos": (cfg.n_audio_ctx, d),
+    }
+    for i in range(cfg.n_enc_layers):
+        p = f"enc.{i}."
+        s.update({p + "ln1.g": (d,), p + "ln1.b": (d,), p + "attn.qkv.w": (3 * d, d), p + "attn.qkv.b": (3 * d,),
+                  p + "attn.out.w": (d, d), p + "attn.out.b": (d,), p + "ln2.g": (d,), p + "ln2.b": (d,),
+                  p + "ffn1.w": (4 * d, d), p + "ffn1.b": (4 * d,), p + "ffn2.w": (d, 4 * d), p + "ffn2.b": (d,)})
+    s.update({"enc.ln_post.g": (d,), "enc.ln_post.b": (d,),
+              "dec.tok_emb": (cfg.n_vocab, d), "dec.pos": (cfg.n_text_ctx, d)})
+    for i in range(cfg.n_dec_layers):
+        p = f"dec.{i}."
+        s.update({p + "ln1.g": (d,), p + "ln1.b": (d,), p + "self.qkv.w": (3 * d, d), p + "self.qkv.b": (3 * d,),
+                  p + "self.out.w": (d, d), p + "self.out.b": (d,), p + "ln2.g": (d,), p + "ln2.b": (d,),
+                  p + "cross.q.w": (d, d), p + "cross.q.b": (d,), p + "cross.kv.w": (2 * d, d),
+                  p + "cross.kv.b": (2 * d,), p + "cross.out.w": (d, d), p + "cross.out.b": (d,),
+                  p + "ln3.g": (d,), p + "ln3.b": (d,), p + "ffn1.w": (4 * d, d), p + "ffn1.b": (4 * d,),
+                  p + "ffn2.w": (d, 4 * d), p + "ffn2.b": (d,)})
+    s.update({"dec.ln.g": (d,), "dec.ln.b": (d,)})
+    return s
+
+
+def sinusoids(length: int, channels: int) -> np.ndarray:
+    """Whisper's fixed encoder positions: [sin | cos] concatenated."""
+    inc = np.log(10000.0) / (channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2))
+    t = np.arange(length)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+
+
+def synthetic_weights(cfg: WhisperConfig, seed: int = 1234, dtype=np.float16) -> Dict[str, np.ndarray]:
+    """Seeded random weights, scaled so activations stay O(1) through 32 layers in fp16.
+    Each tensor has its own stream (seed, crc32(name)), so the values do not depend on
+    generation order.  Values are rounded to `dtype` (fp16 by default = what the engine stores)."""
+    d = cfg.d_model
+    out = {}
+    for name, shape in weight_shapes(cfg).items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        if name == "enc.pos":
+            w = sinusoids(cfg.n_audio_ctx, d)
+        elif name.endswith(".g"):
+            w = 1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
+        elif name.endswith("ln1.b") or name.endswith("ln2.b") or name.endswith("ln3.b") or name.endswith("ln.b") \
+                or name.endswith("ln_post.b"):
+            w = 0.05 * rng.standard_normal(shape, dtype=np.float32)
+        elif name.endswith(".b"):
+            w = 0.02 * rng.standard_normal(shape, dtype=np.float32)
+            if name.endswith("qkv.b"):
+                w[d:2 * d] = 0.0   # Whisper's key projection has no bias
+            if name.endswith("cross.kv.b"):
+                w[:d] = 0.0
+        elif name == "dec.tok_emb":
+            w = 0.05 * rng.standard_normal(shape, dtype=np.float32)
+        elif name == "dec.pos":
+            w = 0.02 * rng.standard_normal(shape, dtype=np.float32)
+        elif name.startswith("enc.conv"):
+            fan_in = shape[1] * shape[2]
+            w = (1.0 / np.sqrt(fan_in)) * rng.standard_normal(shape, dtype=np.float32)
+        else:  # linear [out, in]
+            scale = 0.8 / np.sqrt(shape[1])
+            if name.endswith("ffn2.w") or name.endswith("out.w"):
+                scale *= 0.5  # residual branches: keep the stream from growing
+            w = rng.standard_normal(shape, dtype=np.float32)
+            w *= scale
+        out[name] = np.ascontiguousarray(w.astype(dtype))
+    return out

@@ -1,0 +1,507 @@
+"""CPU restatement of everything behind `ctranslate2.models.Whisper` (test oracle).
+
+PARITY UNPINNED: CTranslate2 (`ctranslate2>=4.0,<5`, /root/reference/requirements.txt:1) is a
+third-party dependency that is not vendored in /root/reference and not installed; this file
+restates its published behaviour (OpenNMT/CTranslate2 4.x `src/models/whisper.cc`,
+`src/layers/whisper.cc`, `src/decoding.cc`; openai/whisper `model.py`, `decoding.py`,
+`timing.py`) and is anchored on the reference's call sites:
+    encode            faster_whisper/transcribe.py:1391-1400
+    generate          transcribe.py:222-236 (batched), :1433-1459 (sequential)
+    score use         transcribe.py:241-246, :1463-1466  (score = cum_logprob / len^length_penalty,
+                      len excludes <|endoftext|>; avg_logprob = cum / (len + 1))
+    detect_language   transcribe.py:215, :1193, :1823-1828
+    align             transcribe.py:1709-1746
+The architecture is cross-checked against the installed `transformers` Whisper
+(tests/test_oracle_arch.py).  Every rule that is remembered rather than verified is tagged
+[CT2-ext].
+
+Numerics: float32 torch on the CPU.  With `emulate_fp16=True` the tensors the GPU engine
+stores in fp16 (weights, activations between kernels, attention probabilities) are rounded
+to fp16 at the same points, so the remaining engine-vs-oracle difference is accumulation
+order only.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def _t(a) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+
+
+@dataclass
+class GenResult:
+    sequences_ids: List[List[int]]
+    scores: List[float]
+    no_speech_prob: float
+    # diagnostics for margin-aware parity checks: per generated step of the best hypothesis,
+    # (top1 - top2) of the processed log-probs along the greedy path (beam_size == 1 only)
+    margins: List[float] = field(default_factory=list)
+
+
+@dataclass
+class AlignResult:
+    alignments: List[tuple]
+    text_token_probs: List[float]
+
+
+def max_new_tokens(max_length: int, prompt_len: int) -> int:
+    """Generated-token budget.  The reference treats `max_length` as prompt + new tokens
+    (transcribe.py:193-207: max_length = len(prompt) + max_new_tokens), so the budget is
+    max_length - len(prompt).  [CT2-ext] CTranslate2 may additionally cap at max_length // 2
+    (openai `sample_len`); unverifiable offline — keep this the single place that decides."""
+    return max(0, max_length - prompt_len)
+
+
+class OracleWhisper:
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_fp16: bool = False, threads: Optional[int] = None):
+        if threads:
+            torch.set_num_threads(threads)
+        self.cfg = cfg
+        self.h = emulate_fp16
+        self.w = {k: self._r(_t(v)) for k, v in weights.items()}
+        d = cfg.d_model
+        self.d, self.H = d, cfg.n_heads
+
+    # fp16 rounding point
+    def _r(self, x: torch.Tensor) -> torch.Tensor:
+        return x.half().float() if self.h else x
+
+    def _ln(self, x, p):
+        return self._r(torch.nn.functional.layer_norm(x, (self.d,), self.w[p + ".g"], self.w[p + ".b"], 1e-5))
+
+    def _lin(self, x, p, act=False, res=None):
+        y = torch.nn.functional.linear(x, self.w[p + ".w"], self.w[p + ".b"])
+        if act:
+            y = torch.nn.functional.gelu(y)  # exact erf GELU
+        if res is not None:
+            y = y + res
+        return self._r(y)
+
+    def _heads(self, x):  # [B, T, d] -> [B, H, T, 64]
+        B, T, _ = x.shape
+        return x.view(B, T, self.H, 64).transpose(1, 2)
+
+    def _attn(self, q, k, v, mask=None, return_probs=False):
+        """q [B,H,Tq,64] (unscaled), k/v [B,H,Tk,64]; softmax(q k^T / 8) v"""
+        s = torch.matmul(q * 0.125, k.transpose(-1, -2))
+        if mask is not None:
+            s = s + mask
+        p = torch.softmax(s, dim=-1)
+        o = torch.matmul(self._r(p), v)
+        B, H, Tq, _ = o.shape
+        o = self._r(o.transpose(1, 2).reshape(B, Tq, H * 64))
+        return (o, p) if return_probs else o
+
+    # ------------------------------------------------------------------ encoder
+    def encode(self, features: np.ndarray) -> np.ndarray:
+        """features float32 [B, n_mels, 3000] -> [B, 1500, d]"""
+        with torch.no_grad():
+            x = self._r(_t(features))
+            x = self._r(torch.nn.functional.gelu(
+                torch.nn.functional.conv1d(x, self.w["enc.conv1.w"], self.w["enc.conv1.b"], padding=1)))
+            x = torch.nn.functional.gelu(
+                torch.nn.functional.conv1d(x, self.w["enc.conv2.w"], self.w["enc.conv2.b"], stride=2, padding=1))
+            x = self._r(x.transpose(1, 2) + self.w["enc.pos"])
+            for i in range(self.cfg.n_enc_layers):
+                p = f"enc.{i}."
+                xn = self._ln(x, p + "ln1")
+                qkv = self._lin(xn, p + "attn.qkv")
+                q, k, v = qkv.split(self.d, dim=-1)
+                a = self._attn(self._heads(q), self._heads(k), self._heads(v))
+                x = self._lin(a, p + "attn.out", res=x)
+                xn = self._ln(x, p + "ln2")
+                hdn = self._lin(xn, p + "ffn1", act=True)
+                x = self._lin(hdn, p + "ffn2", res=x)
+            x = self._ln(x, "enc.ln_post")
+            return x.numpy()
+
+    # ------------------------------------------------------------------ decoder
+    def cross_kv(self, enc: torch.Tensor):
+        out = []
+        for i in range(self.cfg.n_dec_layers):
+            p = f"dec.{i}.cross.kv"
+            kv = self._r(torch.nn.functional.linear(enc, self.w[p + ".w"], self.w[p + ".b"]))
+            k, v = kv.split(self.d, dim=-1)
+            out.append((self._heads(k), self._heads(v)))
+        return out
+
+    def decoder_full(self, tokens: torch.Tensor, ckv, return_cross_probs=False):
+        """teacher-forced pass.  tokens [R, n] (long); ckv per layer ([R,H,1500,64], ...).
+        Returns hidden [R, n, d] after the final LN (and per-layer cross-attn probs)."""
+        R, n = tokens.shape
+        x = self._r(self.w["dec.tok_emb"][tokens] + self.w["dec.pos"][:n])
+        causal = torch.full((n, n), float("-inf")).triu(1)
+        probs = []
+        for i in range(self.cfg.n_dec_layers):
+            p = f"dec.{i}."
+            xn = self._ln(x, p + "ln1")
+            q, k, v = self._lin(xn, p + "self.qkv").split(self.d, dim=-1)
+            a = self._attn(self._heads(q), self._heads(k), self._heads(v), mask=causal)
+            x = self._lin(a, p + "self.out", res=x)
+            xn = self._ln(x, p + "ln2")
+            q = self._lin(xn, p + "cross.q")
+            ck, cv = ckv[i]
+            if return_cross_probs:
+                a, pr = self._attn(self._heads(q), ck, cv, return_probs=True)
+                probs.append(pr)
+            else:
+                a = self._attn(self._heads(q), ck, cv)
+            x = self._lin(a, p + "cross.out", res=x)
+            xn = self._ln(x, p + "ln3")
+            x = self._lin(self._lin(xn, p + "ffn1", act=True), p + "ffn2", res=x)
+        x = self._ln(x, "dec.ln")
+        return (x, probs) if return_cross_probs else x
+
+    def logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.linear(hidden, self.w["dec.tok_emb"])
+
+    class _Cache:
+        """self-attention K/V per layer for R rows, positions filled so far"""
+        def __init__(self, n_layers):
+            self.k = [None] * n_layers
+            self.v = [None] * n_layers
+
+        def reorder(self, idx: torch.Tensor):
+            self.k = [t.index_select(0, idx) for t in self.k]
+            self.v = [t.index_select(0, idx) for t in self.v]
+
+    def decoder_step(self, tok: torch.Tensor, pos: int, cache: "_Cache", ckv):
+        """one position for R rows with KV cache.  tok [R] long -> hidden [R, d]"""
+        x = self._r(self.w["dec.tok_emb"][tok] + self.w["dec.pos"][pos]).unsqueeze(1)
+        for i in range(self.cfg.n_dec_layers):
+            p = f"dec.{i}."
+            xn = self._ln(x, p + "ln1")
+            q, k, v = self._lin(xn, p + "self.qkv").split(self.d, dim=-1)
+            k, v = self._heads(k), self._heads(v)
+            cache.k[i] = k if cache.k[i] is None else torch.cat([cache.k[i], k], dim=2)
+            cache.v[i] = v if cache.v[i] is None else torch.cat([cache.v[i], v], dim=2)
+            a = self._attn(self._heads(q), cache.k[i], cache.v[i])
+            x = self._lin(a, p + "self.out", res=x)
+            xn = self._ln(x, p + "ln2")
+            q = self._lin(xn, p + "cross.q")
+            ck, cv = ckv[i]
+            a = self._attn(self._heads(q), ck, cv)
+            x = self._lin(a, p + "cross.out", res=x)
+            xn = self._ln(x, p + "ln3")
+            x = self._lin(self._lin(xn, p + "ffn1", act=True), p + "ffn2", res=x)
+        return self._ln(x, "dec.ln").squeeze(1)
+
+    # ------------------------------------------------------------------ logits rules
+    def _process_logits(self, logits: np.ndarray, generated: List[int], with_timestamps: bool, suppress_mask,
+                        suppress_blank: bool, max_initial_timestamp_index: int, repetition_penalty: float,
+                        no_repeat_ngram_size: int, min_new_tokens: int) -> np.ndarray:
+        """one row: raw logits [V] float32 -> processed log-probs [V] float32."""
+        c = self.cfg
+        lg = logits.astype(np.float32).copy()
+        NEG = np.float32(-np.inf)
+        n = len(generated)
+        if repetition_penalty != 1.0 and n:                       # CT2 RepetitionPenalty
+            ids = np.unique(np.asarray(generated))
+            v = lg[ids]
+            lg[ids] = np.where(v < 0, v * np.float32(repetition_penalty), v / np.float32(repetition_penalty))
+        if no_repeat_ngram_size > 0 and n + 1 >= no_repeat_ngram_size:   # CT2 NoRepeatNgram
+            k = no_repeat_ngram_size
+            prefix = tuple(generated[n - (k - 1):]) if k > 1 else ()
+            for s in range(0, n - k + 1):
+                if tuple(generated[s:s + k - 1]) == prefix:
+                    lg[generated[s + k - 1]] = NEG
+        if suppress_blank and n == 0:                             # SuppressTokensBegin
+            for t in c.suppress_begin:
+                lg[t] = NEG
+        if suppress_mask is not None:                             # SuppressTokens
+            lg[suppress_mask] = NEG
+        if n < min_new_tokens:                                    # benchmark-only control
+            lg[c.eot] = NEG
+        if with_timestamps:                                       # ApplyTimestampRules
+            tb = c.timestamp_begin
+            lg[c.no_timestamps] = NEG
+            last_ts = n >= 1 and generated[-1] >= tb
+            penult_ts = n < 2 or generated[-2] >= tb
+            if last_ts:
+                if penult_ts:
+                    lg[tb:] = NEG
+                else:
+                    lg[:c.eot] = NEG
+            ts = [t for t in generated if t >= tb]
+            if ts:
+                last = ts[-1] if (last_ts and not penult_ts) else ts[-1] + 1
+                lg[tb:last] = NEG
+            if n == 0:
+                lg[:tb] = NEG
+                if max_initial_timestamp_index is not None and max_initial_timestamp_index >= 0:
+                    lg[tb + max_initial_timestamp_index + 1:] = NEG
+            lp = _log_softmax(lg)
+            ts_lp = _logsumexp(lp[tb:])
+            if ts_lp > lp[:tb].max():
+                lg[:tb] = NEG
+        return _log_softmax(lg)
+
+    # ------------------------------------------------------------------ generate
+    def generate(self, enc: np.ndarray, prompts: Sequence[Sequence[int]], beam_size=5, patience=1.0,
+                 num_hypotheses=1, length_penalty=1.0, repetition_penalty=1.0, no_repeat_ngram_size=0,
+                 max_length=448, return_scores=True, return_no_speech_prob=True, max_initial_timestamp_index=50,
+                 suppress_blank=True, suppress_tokens=None, sampling_topk=1, sampling_temperature=1.0,
+                 min_new_tokens=0, force_tokens: Optional[Sequence[Sequence[int]]] = None) -> List[GenResult]:
+        """CTranslate2 Whisper.generate semantics (greedy for beam_size == 1, beam search otherwise).
+        force_tokens: teacher forcing for margin diagnostics (greedy only): the chosen token at each
+        step is taken from this list instead of the argmax."""
+        c = self.cfg
+        enc_t = self._r(_t(enc))
+        sup = None
+        if suppress_tokens is not None:
+            ids = [t for t in suppress_tokens if 0 <= t < c.n_vocab]
+            if ids:
+                sup = np.asarray(sorted(set(ids)), dtype=np.int64)
+        out = []
+        with torch.no_grad():
+            for b, prompt in enumerate(prompts):
+                out.append(self._generate_one(enc_t[b:b + 1], list(prompt), beam_size, patience, num_hypotheses,
+                                              length_penalty, repetition_penalty, no_repeat_ngram_size, max_length,
+                                              max_initial_timestamp_index, suppress_blank, sup, min_new_tokens,
+                                              force_tokens[b] if force_tokens is not None else None))
+        return out
+
+    def _generate_one(self, enc1, prompt, K, patience, num_hyp, lp_pow, rep_pen, ngram, max_length, mits,
+                      suppress_blank, sup, min_new, forced):
+        c = self.cfg
+        P = len(prompt)
+        budget = max_new_tokens(max_length, P)
+        with_ts = c.no_timestamps not in prompt
+        ckv1 = self.cross_kv(enc1)
+        # ---- prompt forward (all but the last token), no_speech at the <sot> position
+        cache = self._Cache(c.n_dec_layers)
+        no_speech = 0.0
+        sot_pos = max((i for i, t in enumerate(prompt) if t == c.sot), default=-1)
+        for pos in range(P - 1):
+            h = self.decoder_step(torch.tensor([prompt[pos]]), pos, cache, ckv1)
+            if pos == sot_pos:
+                pr = torch.softmax(self.logits(h)[0], dim=-1)
+                no_speech = float(pr[c.no_speech])
+        # ---- first real step: the last prompt token, one row
+        h = self.decoder_step(torch.tensor([prompt[P - 1]]), P - 1, cache, ckv1)
+        if sot_pos == P - 1:
+            no_speech = float(torch.softmax(self.logits(h)[0], dim=-1)[c.no_speech])
+        logits = self.logits(h).numpy()
+        if budget == 0:
+            return GenResult([[]], [0.0], no_speech)
+
+        def proc(lg_row, gen):
+            return self._process_logits(lg_row, gen, with_ts, sup, suppress_blank, mits, rep_pen, ngram, min_new)
+
+        if K == 1:
+            return self._greedy(cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced)
+
+        # ---------------- beam search [CT2-ext: BeamSearch::search in src/decoding.cc] ----------------
+        ckv = [(k.expand(K, -1, -1, -1), v.expand(K, -1, -1, -1)) for k, v in ckv1]
+        max_fin = max(1, int(round(K * patience)))
+        beams = [[] for _ in range(K)]          # generated tokens per live beam
+        cum = np.zeros(K, dtype=np.float32)
+        finished = []                           # (score, tokens, cum)
+        n_live_src = 1                          # first step expands from beam 0 only
+        V = c.n_vocab
+        step = 0
+        cache.reorder(torch.zeros(K, dtype=torch.long))
+        while True:
+            # candidates: top 2K of cum[k] + logp[k][v], ties -> lowest flat index
+            lp = np.stack([proc(logits[k], beams[k]) for k in range(n_live_src)])
+            flat = (cum[:n_live_src, None] + lp).reshape(-1)
+            order = _topk_stable(flat, 2 * K)
+            last_step = (step + 1) >= budget
+            new_beams, new_cum, parents, new_tok = [], [], [], []
+            sec = K                              # secondary candidate cursor
+            for slot in range(K):
+                j = slot
+                cand = order[j] if j < len(order) else None
+                if cand is not None and np.isfinite(flat[cand]) and (cand % V == c.eot or last_step):
+                    kk, vv = divmod(int(cand), V)
+                    toks = beams[kk] + ([] if vv == c.eot else [vv])
+                    finished.append(_hyp(flat[cand], toks, lp_pow))
+                    if last_step:
+                        continue
+                    # replace by the next non-eot secondary candidate
+                    while sec < len(order) and order[sec] % V == c.eot:
+                        sec += 1
+                    j = sec
+                    sec += 1
+                    cand = order[j] if j < len(order) else None
+                if cand is None:
+                    continue
+                kk, vv = divmod(int(cand), V)
+                new_beams.append(beams[kk] + [vv])
+                new_cum.append(flat[cand])
+                parents.append(kk)
+                new_tok.append(vv)
+            step += 1
+            if last_step or len(finished) >= max_fin or not new_beams:
+                break
+            while len(new_beams) < K:           # degenerate (fewer than K finite candidates): pad with dead beams
+                new_beams.append(list(new_beams[0])); new_cum.append(np.float32(-np.inf))
+                parents.append(parents[0]); new_tok.append(new_tok[0])
+            beams, cum = new_beams, np.asarray(new_cum, dtype=np.float32)
+            cache.reorder(torch.tensor(parents, dtype=torch.long))
+            h = self.decoder_step(torch.tensor(new_tok), P - 1 + step, cache, ckv)
+            logits = self.logits(h).numpy()
+            n_live_src = K
+        finished.sort(key=lambda t: -t[0])      # stable: earlier-finished first among equal scores
+        best = finished[:max(1, num_hyp)]
+        return GenResult([t[1] for t in best], [float(t[0]) for t in best], no_speech)
+
+    def _greedy(self, cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced):
+        c = self.cfg
+        gen, margins = [], []
+        cum = np.float32(0.0)
+        step = 0
+        ended = False
+        while step < budget:
+            lp = proc(logits[0], gen)
+            order = _topk_stable(lp, 2)
+            tok = int(order[0])
+            margins.append(float(lp[order[0]] - lp[order[1]]))
+            if forced is not None and step < len(forced):
+                tok = int(forced[step])
+            cum = np.float32(cum + lp[tok])
+            step += 1
+            if tok == c.eot:
+                ended = True
+                break
+            gen.append(tok)
+            if step >= budget:
+                break
+            h = self.decoder_step(torch.tensor([tok]), P - 1 + step, cache, ckv1)
+            logits = self.logits(h).numpy()
+        score = _hyp(cum, gen, lp_pow)[0]
+        return GenResult([gen], [float(score)], no_speech, margins)
+
+    # ------------------------------------------------------------------ detect_language
+    def detect_language(self, enc: np.ndarray):
+        """one decoder step on [sot]; softmax over the language ids only; sorted descending
+        (ties: lower id first).  Returns per row a list of (token_id, prob)."""
+        c = self.cfg
+        with torch.no_grad():
+            enc_t = self._r(_t(enc))
+            ckv = self.cross_kv(enc_t)
+            B = enc_t.shape[0]
+            cache = self._Cache(c.n_dec_layers)
+            h = self.decoder_step(torch.full((B,), c.sot, dtype=torch.long), 0, cache, ckv)
+            lg = self.logits(h)[:, c.lang_begin:c.lang_begin + c.n_langs]
+            pr = torch.softmax(lg, dim=-1).numpy()
+        out = []
+        for b in range(B):
+            order = _topk_stable(pr[b], c.n_langs)
+            out.append([(int(c.lang_begin + i), float(pr[b, i])) for i in order])
+        return out
+
+    # ------------------------------------------------------------------ align
+    def alignment_heads(self):
+        c = self.cfg
+        if c.alignment_heads:
+            return [tuple(x) for x in c.alignment_heads]
+        # [CT2-ext] default: every head of the upper half of the decoder
+        return [(l, h) for l in range(c.n_dec_layers // 2, c.n_dec_layers) for h in range(c.n_heads)]
+
+    def align(self, enc: np.ndarray, start_sequence: Sequence[int], text_tokens: Sequence[Sequence[int]],
+              num_frames, median_filter_width: int = 7) -> List[AlignResult]:
+        """openai-whisper timing.find_alignment / CTranslate2 Whisper.align."""
+        c = self.cfg
+        B = enc.shape[0]
+        nfs = [num_frames] * B if isinstance(num_frames, int) else list(num_frames)
+        heads = self.alignment_heads()
+        out = []
+        with torch.no_grad():
+            enc_t = self._r(_t(enc))
+            for b in range(B):
+                text = list(text_tokens[b])
+                toks = list(start_sequence) + [c.no_timestamps] + text + [c.eot]
+                ckv = self.cross_kv(enc_t[b:b + 1])
+                hidden, probs = self.decoder_full(torch.tensor([toks]), ckv, return_cross_probs=True)
+                n0 = len(start_sequence) + 1
+                lg = self.logits(hidden[0, n0 - 1:n0 - 1 + len(text)])
+                tp = torch.softmax(lg, dim=-1)
+                text_probs = [float(tp[i, t]) for i, t in enumerate(text)]
+                nfr = min(c.n_audio_ctx, max(1, nfs[b] // 2))
+                w = torch.stack([probs[l][0, h] for (l, h) in heads])[:, :, :nfr]   # [heads, tokens, frames]
+                mean = w.mean(dim=-2, keepdim=True)
+                std = w.std(dim=-2, keepdim=True, unbiased=False)
+                w = (w - mean) / std
+                w = _median_filter(w.numpy(), median_filter_width)
+                m = w.mean(axis=0)[n0:-1]                                            # text rows only
+                ti, fi = _dtw(-m.astype(np.float64))
+                out.append(AlignResult(list(zip(ti.tolist(), fi.tolist())), text_probs))
+        return out
+
+
+# ---------------------------------------------------------------------- helpers
+def _log_softmax(x: np.ndarray) -> np.ndarray:
+    m = x.max()
+    if not np.isfinite(m):
+        return np.full_like(x, -np.inf)
+    e = np.exp((x - m).astype(np.float32), dtype=np.float32)
+    return (x - m - np.log(e.sum(dtype=np.float32))).astype(np.float32)
+
+
+def _logsumexp(x: np.ndarray) -> np.float32:
+    m = x.max()
+    if not np.isfinite(m):
+        return np.float32(-np.inf)
+    return np.float32(m + np.log(np.exp((x - m).astype(np.float32)).sum(dtype=np.float32)))
+
+
+def _topk_stable(x: np.ndarray, k: int) -> np.ndarray:
+    """indices of the k largest values, descending; ties -> lowest index first"""
+    k = min(k, x.shape[0])
+    idx = np.argsort(-x, kind="stable")[:k]
+    return idx
+
+
+def _hyp(cum, toks, lp_pow):
+    n = max(1, len(toks))
+    score = np.float32(cum) / np.float32(n ** lp_pow) if lp_pow != 0 else np.float32(cum)
+    return (float(score), list(toks), float(cum))
+
+
+def _median_filter(x: np.ndarray, width: int) -> np.ndarray:
+    """median filter along the last axis with reflect padding (openai timing.median_filter)"""
+    pad = width // 2
+    if pad == 0 or x.shape[-1] <= pad:
+        return x
+    xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(pad, pad)], mode="reflect")
+    win = np.lib.stride_tricks.sliding_window_view(xp, width, axis=-1)
+    return np.sort(win, axis=-1)[..., pad]
+
+
+def _dtw(cost: np.ndarray):
+    """openai timing.dtw_cpu: D[i,j] = cost + min(diag, up, left); ties prefer diag, then up (i-1), then left."""
+    N, M = cost.shape
+    D = np.full((N + 1, M + 1), np.inf)
+    tr = -np.ones((N + 1, M + 1), dtype=np.int8)
+    D[0, 0] = 0
+    for j in range(1, M + 1):
+        for i in range(1, N + 1):
+            c0, c1, c2 = D[i - 1, j - 1], D[i - 1, j], D[i, j - 1]
+            if c0 < c1 and c0 < c2:
+                cc, t = c0, 0
+            elif c1 < c0 and c1 < c2:
+                cc, t = c1, 1
+            else:
+                cc, t = c2, 2
+            D[i, j] = cost[i - 1, j - 1] + cc
+            tr[i, j] = t
+    i, j = N, M
+    tr[0, :] = 2
+    tr[:, 0] = 1
+    path = []
+    while i > 0 or j > 0:
+        path.append((i - 1, j - 1))
+        t = tr[i, j]
+        if t == 0:
+            i -= 1; j -= 1
+        elif t == 1:
+            i -= 1
+        else:
+            j -= 1
+    path = np.array(path[::-1])
+    return path[:, 0], path[:, 1]

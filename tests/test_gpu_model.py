@@ -1,0 +1,210 @@
+"""End-to-end parity of the HIP engine (through the ctranslate2-compatible front and the C ABI)
+against the CPU oracle on seeded synthetic weights: encode, generate (greedy + beam),
+detect_language, align.
+
+The oracle is run with fp16 rounding emulated at the engine's storage points, so what is left
+is accumulation-order noise.  Token ids must match bit-exactly wherever the oracle's own
+top-1/top-2 margin exceeds MARGIN (a flip at a smaller margin is fp noise, not a bug);
+scores / probabilities within 1e-3 (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import bench_audio, make_model
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 2e-2
+
+
+@pytest.fixture(scope="module", params=["micro", "tiny.en"])
+def setup(request):
+    from oracle.whisper import OracleWhisper
+    cfg, w, model = make_model(request.param, seed=11, max_batch=4, max_beam=5)
+    oracle = OracleWhisper(cfg, w, emulate_fp16=True)
+    chunks = [bench_audio(480000, seed=1), bench_audio(200000, seed=2), bench_audio(480000, seed=3)[::-1].copy()]
+    feats = model.log_mel(chunks)
+    return cfg, model, oracle, feats
+
+
+def _prompt(cfg, timestamps=False):
+    p = list(cfg.sot_sequence)
+    if not timestamps:
+        p.append(cfg.no_timestamps)
+    return p
+
+
+def _suppress(cfg):
+    return sorted({cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe, 1, 2, 7})
+
+
+def test_encode(setup):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    assert enc.shape == [3, 1500, cfg.d_model]
+    got = enc.to_numpy()
+    ref = oracle.encode(feats)
+    err = float(np.abs(got - ref).max())
+    rel = err / float(np.abs(ref).max())
+    print(f"[{cfg.name}] encoder: max abs err {err:.3e} (rel {rel:.2e}), ref absmax {np.abs(ref).max():.2f}")
+    assert rel < 1e-2
+    # fused resident path == host-features path
+    chunks = [bench_audio(480000, seed=1), bench_audio(200000, seed=2), bench_audio(480000, seed=3)[::-1].copy()]
+    enc2 = model.encode_pcm(chunks).to_numpy()
+    err2 = float(np.abs(enc2 - got).max())
+    print(f"[{cfg.name}] encode_pcm vs encode(features): {err2:.3e}")
+    assert err2 < 2e-2 * max(1.0, float(np.abs(ref).max()))
+
+
+def _check_ids(got, ref):
+    """ids must agree up to the first step where the oracle's margin is below MARGIN"""
+    n = 0
+    while n < len(ref.sequences_ids[0]) and n < len(ref.margins) and ref.margins[n] > MARGIN:
+        n += 1
+    assert got.sequences_ids[0][:n] == ref.sequences_ids[0][:n], (got.sequences_ids[0], ref.sequences_ids[0], ref.margins)
+    return n, got.sequences_ids[0] == ref.sequences_ids[0]
+
+
+@pytest.mark.parametrize("timestamps", [False, True])
+def test_generate_greedy(setup, timestamps):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()   # feed the oracle the engine's own encoder output: isolates the decoder
+    prompt = _prompt(cfg, timestamps)
+    L = 24
+    kw = dict(beam_size=1, max_length=len(prompt) + L, suppress_blank=True, suppress_tokens=_suppress(cfg),
+              max_initial_timestamp_index=50)
+    got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+    ref = oracle.generate(enc_np, [prompt] * 3, **kw)
+    full = 0
+    for b, (g, r) in enumerate(zip(got, ref)):
+        n, same = _check_ids(g, r)
+        full += same
+        print(f"[{cfg.name}] greedy ts={timestamps} chunk {b}: {n}/{len(r.sequences_ids[0])} margin-safe ids equal, "
+              f"all equal={same}, score {g.scores[0]:.5f} vs {r.scores[0]:.5f}, "
+              f"no_speech {g.no_speech_prob:.3e} vs {r.no_speech_prob:.3e}")
+        if same:
+            assert abs(g.scores[0] - r.scores[0]) < 1e-3 * max(1.0, abs(r.scores[0]))
+        assert abs(g.no_speech_prob - r.no_speech_prob) < 1e-3
+    assert full >= 2  # noise-level flips must be the exception
+
+
+def test_generate_teacher_forced_logprobs(setup):
+    """per-step parity independent of argmax ties: force the oracle along the engine's ids and compare
+    the cumulative log-prob"""
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    prompt = _prompt(cfg)
+    L = 16
+    kw = dict(beam_size=1, max_length=len(prompt) + L, suppress_tokens=_suppress(cfg), length_penalty=0.0)
+    got = model.generate(enc, [prompt] * 3, return_scores=True, **kw)
+    ref = oracle.generate(enc_np, [prompt] * 3, force_tokens=[g.sequences_ids[0] for g in got], **kw)
+    for g, r in zip(got, ref):
+        assert r.sequences_ids[0] == g.sequences_ids[0]
+        print(f"[{cfg.name}] teacher-forced cum logprob {g.scores[0]:.5f} vs {r.scores[0]:.5f}")
+        assert abs(g.scores[0] - r.scores[0]) < 2e-3 * max(1.0, abs(r.scores[0]))
+
+
+@pytest.mark.parametrize("beam,timestamps", [(5, False), (5, True), (2, False)])
+def test_generate_beam(setup, beam, timestamps):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    prompt = _prompt(cfg, timestamps)
+    L = 16
+    kw = dict(beam_size=beam, patience=1.0, length_penalty=1.0, max_length=len(prompt) + L,
+              suppress_tokens=_suppress(cfg))
+    got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+    ref = oracle.generate(enc_np, [prompt] * 3, **kw)
+    same = 0
+    for b, (g, r) in enumerate(zip(got, ref)):
+        eq = g.sequences_ids[0] == r.sequences_ids[0]
+        same += eq
+        print(f"[{cfg.name}] beam={beam} ts={timestamps} chunk {b}: ids equal={eq} score {g.scores[0]:.5f} vs {r.scores[0]:.5f}")
+        # avg_logprob as the reference host computes it (transcribe.py:241-246)
+        assert abs(g.scores[0] - r.scores[0]) < 1e-3 * max(1.0, abs(r.scores[0])) or not eq
+        assert abs(g.no_speech_prob - r.no_speech_prob) < 1e-3
+    assert same >= 2
+
+
+def test_generate_eot_and_early_finish(setup):
+    """make <eot> very likely after a few tokens via min_new_tokens=0 and a tiny budget: exercises
+    finished-hypothesis bookkeeping and the max-length finalisation"""
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    prompt = _prompt(cfg)
+    for beam in (1, 3):
+        kw = dict(beam_size=beam, max_length=len(prompt) + 3, suppress_tokens=None, suppress_blank=False)
+        got = model.generate(enc, [prompt] * 3, return_scores=True, **kw)
+        ref = oracle.generate(enc_np, [prompt] * 3, **kw)
+        for g, r in zip(got, ref):
+            assert len(g.sequences_ids[0]) <= 3
+            print(f"[{cfg.name}] budget-3 beam={beam}: {g.sequences_ids[0]} vs {r.sequences_ids[0]}")
+
+
+def test_generate_argument_errors(setup):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    with pytest.raises(ValueError):
+        model.generate(enc, [[cfg.sot]] * 2)                      # wrong number of prompts
+    with pytest.raises(ValueError):
+        model.generate(enc, [[cfg.sot], [cfg.sot, cfg.sot], [cfg.sot]])  # ragged prompts
+    with pytest.raises(ValueError):
+        model.generate(enc, [[cfg.sot]] * 3, beam_size=99)
+    with pytest.raises(ValueError):
+        model.encode(StorageView.from_array(np.zeros((1, cfg.n_mels, 100), np.float32)))
+
+
+def test_detect_language(setup):
+    from faster_whisper_amd.backend import StorageView, language_token_strings
+    cfg, model, oracle, feats = setup
+    if not cfg.is_multilingual:
+        with pytest.raises(RuntimeError):
+            model.detect_language(StorageView.from_array(feats))
+        return
+    enc = model.encode(StorageView.from_array(feats))
+    got = model.detect_language(enc)
+    ref = oracle.detect_language(enc.to_numpy())
+    names = language_token_strings(cfg)
+    for g, r in zip(got, ref):
+        assert len(g) == cfg.n_langs
+        assert abs(sum(p for _, p in g) - 1.0) < 1e-4
+        gp = {tok: p for tok, p in g}
+        for tid, p in r:
+            assert abs(gp[names[tid - cfg.lang_begin]] - p) < 1e-3
+        print(f"[{cfg.name}] detect_language top: {g[0]} vs {(names[r[0][0] - cfg.lang_begin], r[0][1])}")
+
+
+def test_align(setup):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    rng = np.random.default_rng(4)
+    text = [rng.integers(10, 300, size=n).tolist() for n in (12, 5, 20)]
+    num_frames = [3000, 1250, 2000]
+    got = model.align(enc, cfg.sot_sequence, text, num_frames, median_filter_width=7)
+    ref = oracle.align(enc_np, cfg.sot_sequence, text, num_frames, median_filter_width=7)
+    for b, (g, r) in enumerate(zip(got, ref)):
+        pe = float(np.abs(np.array(g.text_token_probs) - np.array(r.text_token_probs)).max())
+        # DTW paths are discrete: compare the word-boundary times the reference derives from them
+        gt = np.array([t for _, t in g.alignments])
+        rt = np.array([t for _, t in r.alignments])
+        gi = np.array([i for i, _ in g.alignments])
+        ri = np.array([i for i, _ in r.alignments])
+        gj = gt[np.r_[True, np.diff(gi) > 0]]
+        rj = rt[np.r_[True, np.diff(ri) > 0]]
+        assert len(gj) == len(rj) == len(text[b])
+        jd = int(np.abs(gj - rj).max())
+        print(f"[{cfg.name}] align chunk {b}: token prob err {pe:.2e}, max jump-time diff {jd} frames, "
+              f"path len {len(g.alignments)} vs {len(r.alignments)}")
+        assert pe < 1e-3
+        assert gi[-1] == len(text[b]) - 1 and gt[-1] == num_frames[b] // 2 - 1
+        assert jd <= 2
