@@ -80,9 +80,11 @@ def synthetic_weights(cfg: WhisperConfig, seed: int = 1234, dtype=np.float16) ->
             if name.endswith("cross.kv.b"):
                 w[:d] = 0.0
         elif name == "dec.tok_emb":
-            w = 0.05 * rng.standard_normal(shape, dtype=np.float32)
+            # tied input/output embedding: keep it small next to the positions, otherwise the
+            # "repeat the input token" attractor makes every synthetic transcript constant
+            w = 0.1 * rng.standard_normal(shape, dtype=np.float32)
         elif name == "dec.pos":
-            w = 0.02 * rng.standard_normal(shape, dtype=np.float32)
+            w = 0.6 * rng.standard_normal(shape, dtype=np.float32)
         elif name.startswith("enc.conv"):
             fan_in = shape[1] * shape[2]
             w = (1.0 / np.sqrt(fan_in)) * rng.standard_normal(shape, dtype=np.float32)
