@@ -35,67 +35,164 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
 
 // ------------------------------------------------------------------------------------
 // K13/K15/K16: skinny GEMM  out[r][n] = epi( sum_k x[r][k] W[n][k] ),  r < R <= 16*MT
-// Weight-streaming kernel: one workgroup owns 16 output columns; its 4 waves split K and
-// reduce through LDS in a fixed order (deterministic).  v_mfma_f32_16x16x32_f16 with
-// A = W rows (n), B = x rows, so a lane ends with 4 consecutive n of one row.
+//
+// Weight-streaming kernel (HBM-bound: every weight byte is read exactly once per step).
+// One workgroup owns 16*NTW output columns; its 4 waves split K and reduce through LDS in
+// a fixed order (deterministic).  v_mfma_f32_16x16x32_f16 with A = W rows (n), B = x rows,
+// so a lane ends with 4 consecutive n of one row.  The K loop is software-pipelined by
+// hand: two register sets of CH k-steps each, the loads of the next chunk (W from HBM, x
+// from L2) are all issued before the MFMAs of the current one, so >= CH*(NTW+MT) 16-byte
+// loads per lane are always in flight (a step is latency-bound otherwise).
+//
+// LNF: the LayerNorm that precedes this linear is folded in (decoder rows are few, a
+// LayerNorm launch would be pure launch overhead).  With wf = W.g (packed at load time):
+//      y = rstd_r * ( wf x_r - mu_r * s1 ) + cf
+// mu/rstd come from sum / sum-of-squares of the raw x fragments the lanes hold anyway
+// (v_dot2c_f32_f16), reduced over the 4 k-groups of a row and the 4 waves.
 // ------------------------------------------------------------------------------------
-template <int MT, bool OUT_F32>
+template <int MT, int NTW, int CH>
+struct DgFrag {
+  half8_t w[CH][NTW];
+  half8_t x[CH][MT];
+};
+
+template <int MT, int NTW, int CH, bool LNF, bool OUT_F32>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict__ x, int ldx,
                                                        const half_t* __restrict__ W,
                                                        const half_t* __restrict__ bias,
+                                                       const float* __restrict__ s1, const float* __restrict__ cf,
                                                        const half_t* __restrict__ res, int ldr, void* __restrict__ outv,
                                                        int ldo, int R, int N, int K, int act) {
-  __shared__ float red[4][MT][64][4];
+  extern __shared__ __attribute__((aligned(16))) float dg_smem[];
+  float* red = dg_smem;                                  // [4][MT*NTW][64][4]
+  float* stat = dg_smem + 4 * MT * NTW * 256;            // [4][MT][16][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * (16 * NTW);
   const int kq = K >> 2;  // per-wave K range
   const int kbase = wave * kq + g * 8;
-  int wrow = n0 + i; if (wrow > N - 1) wrow = N - 1;
-  const half_t* wp = W + (size_t)wrow * K + kbase;
+  const int steps = kq >> 5;
+  const half_t* wp[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    int wrow = n0 + t * 16 + i; if (wrow > N - 1) wrow = N - 1;
+    wp[t] = W + (size_t)wrow * K + kbase;
+  }
   const half_t* xp[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int xr = mt * 16 + i; if (xr > R - 1) xr = R - 1;
     xp[mt] = x + (size_t)xr * ldx + kbase;
   }
-  floatx4 acc[MT];
+  floatx4 acc[MT][NTW];
+  float rs[MT], rq[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0, 0, 0, 0};
-  const int steps = kq >> 5;
-#pragma unroll 4
-  for (int ks = 0; ks < steps; ++ks) {
-    const half8_t wf = *reinterpret_cast<const half8_t*>(wp + ks * 32);
+  for (int mt = 0; mt < MT; ++mt) {
+    rs[mt] = 0.f; rq[mt] = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const half8_t xf = *reinterpret_cast<const half8_t*>(xp[mt] + ks * 32);
-      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[mt], 0, 0, 0);
-    }
+    for (int t = 0; t < NTW; ++t) acc[mt][t] = floatx4{0, 0, 0, 0};
   }
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load = [&](DgFrag<MT, NTW, CH>& f, int ks0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int ks = ks0 + j;
+      if (ks < steps) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) f.w[j][t] = *reinterpret_cast<const half8_t*>(wp[t] + ks * 32);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) f.x[j][mt] = *reinterpret_cast<const half8_t*>(xp[mt] + ks * 32);
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) f.w[j][t] = zero8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) f.x[j][mt] = zero8;
+      }
+    }
+  };
+  auto compute = [&](const DgFrag<MT, NTW, CH>& f) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[j][t], f.x[j][mt], acc[mt][t], 0, 0, 0);
+        if (LNF) {
+          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2_t h2 = {f.x[j][mt][2 * e], f.x[j][mt][2 * e + 1]};
+            rs[mt] = __builtin_amdgcn_fdot2(h2, one2, rs[mt], false);
+            rq[mt] = __builtin_amdgcn_fdot2(h2, h2, rq[mt], false);
+          }
+        }
+      }
+  };
+  DgFrag<MT, NTW, CH> fa, fb;
+  load(fa, 0);
+  for (int ks0 = 0; ks0 < steps; ks0 += 2 * CH) {
+    load(fb, ks0 + CH);
+    compute(fa);
+    load(fa, ks0 + 2 * CH);
+    compute(fb);
+  }
+  // ---- cross-wave reduction (fixed order) ----
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][mt][lane][e] = acc[mt][e];
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[((wave * MT * NTW + mt * NTW + t) * 64 + lane) * 4 + e] = acc[mt][t][e];
+  if (LNF) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float a = rs[mt], b = rq[mt];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (g == 0) {
+        stat[((wave * MT + mt) * 16 + i) * 2] = a;
+        stat[((wave * MT + mt) * 16 + i) * 2 + 1] = b;
+      }
+    }
+  }
   __syncthreads();
-  for (int mt = wave; mt < MT; mt += 4) {
+  for (int idx = wave; idx < MT * NTW; idx += 4) {
+    const int mt = idx / NTW, t = idx - mt * NTW;
     const int row = mt * 16 + i;
     if (row >= R) continue;
-    const int n = n0 + 4 * g;
+    const int n = n0 + t * 16 + 4 * g;
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      v[e] = ((red[0][mt][lane][e] + red[1][mt][lane][e]) + red[2][mt][lane][e]) + red[3][mt][lane][e];
+    for (int e = 0; e < 4; ++e) {
+      const int o = (idx * 64 + lane) * 4 + e;
+      const int ws = MT * NTW * 256;
+      v[e] = ((red[o] + red[ws + o]) + red[2 * ws + o]) + red[3 * ws + o];
+    }
+    float mu = 0.f, rstd = 1.f;
+    if (LNF) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        sa += stat[((w * MT + mt) * 16 + i) * 2];
+        sb += stat[((w * MT + mt) * 16 + i) * 2 + 1];
+      }
+      mu = sa / (float)K;
+      const float var = fmaxf(sb / (float)K - mu * mu, 0.f);
+      rstd = rsqrtf(var + 1e-5f);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e >= N) continue;
-      float t = v[e];
-      if (bias) t += (float)bias[n + e];
-      if (act == 1) t = gelu_erf(t);
-      if (res) t += (float)res[(size_t)row * ldr + n + e];
+      float tv = v[e];
+      if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
+      else if (bias) tv += (float)bias[n + e];
+      if (act == 1) tv = gelu_erf(tv);
+      if (res) tv += (float)res[(size_t)row * ldr + n + e];
       if (OUT_F32)
-        reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = t;
+        reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = tv;
       else
-        reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)t;
+        reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)tv;
     }
   }
 }
@@ -104,6 +201,8 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict_
 // K13: decoder self-attention for one (row, head), KV cache with slot indirection.
 // cache layout [slot][H][n_ctx][64].  The new K/V (position pos) are written to the row's
 // own slot; older positions are read from kvidx[row][p] (slot inside the chunk).
+// QK: one key per lane (128-byte row = 8 x 16-byte loads); PV: 8 lanes cover the 128-byte
+// V row of a position (16 bytes each), 8 position groups in flight, shuffle-reduced.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
                                                            half_t* __restrict__ vc, int n_ctx, int H,
@@ -136,13 +235,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
     const int src = c * Kbeam + kvidx[p];
     ssrc[p] = src;
     const half8_t* kr = reinterpret_cast<const half8_t*>(kc + src * slot_stride + h * head_stride + (size_t)p * 64);
+    half8_t kv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kv[j] = kr[j];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const half8_t kv = kr[j];
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += sq[j * 8 + e] * (float)kv[e];
-    }
+      for (int e = 0; e < 8; ++e) s += sq[j * 8 + e] * (float)kv[j][e];
     sp[p] = s;
     mx = fmaxf(mx, s);
   }
@@ -156,19 +256,34 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
   const float e_new = __expf(s_new - mx);
   sum = wave_sum(sum) + e_new;
   __syncthreads();
-  float acc = 0.f;
-  const half_t* vb = vc + h * head_stride + lane;
-  int p = 0;
-  for (; p + 4 <= pos; p += 4) {
-    const float v0 = (float)vb[ssrc[p] * slot_stride + (size_t)p * 64];
-    const float v1 = (float)vb[ssrc[p + 1] * slot_stride + (size_t)(p + 1) * 64];
-    const float v2 = (float)vb[ssrc[p + 2] * slot_stride + (size_t)(p + 2) * 64];
-    const float v3 = (float)vb[ssrc[p + 3] * slot_stride + (size_t)(p + 3) * 64];
-    acc += sp[p] * v0 + sp[p + 1] * v1 + sp[p + 2] * v2 + sp[p + 3] * v3;
+  const int pg = lane >> 3, cc = lane & 7;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const half_t* vb = vc + h * head_stride + cc * 8;
+#pragma unroll 4
+  for (int p = pg; p < pos; p += 8) {
+    const half8_t vv = *reinterpret_cast<const half8_t*>(vb + ssrc[p] * slot_stride + (size_t)p * 64);
+    const float w = sp[p];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += w * (float)vv[e];
   }
-  for (; p < pos; ++p) acc += sp[p] * (float)vb[ssrc[p] * slot_stride + (size_t)p * 64];
-  acc += e_new * (float)vnew;
-  out[(size_t)r * d + h * 64 + lane] = (half_t)(acc / sum);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float a = acc[e];
+    a += __shfl_xor(a, 8, 64);
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    acc[e] = a;
+  }
+  if (pg == 0) {
+    const half8_t vn = *reinterpret_cast<const half8_t*>(qr + 2 * d + cc * 8);
+    const float inv = 1.f / sum;
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((acc[e] + e_new * (float)vn[e]) * inv);
+    *reinterpret_cast<half8_t*>(out + (size_t)r * d + h * 64 + cc * 8) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -352,6 +467,7 @@ static __device__ __forceinline__ PairMS pair_wave(PairMS a) {
   return a;
 }
 
+#define LP_NV 56 /* values per thread kept in registers: V <= 56*1024 */
 __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::GenDev gp, float* __restrict__ logits,
                                                                         const uint8_t* __restrict__ sup_mask,
                                                                         const int* __restrict__ hist2,
@@ -361,7 +477,6 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
                                                                         float* __restrict__ cand_val,
                                                                         int* __restrict__ cand_tok) {
   __shared__ PairMS red_t[LP_THREADS / 64], red_s[LP_THREADS / 64];
-  __shared__ float red_mt[LP_THREADS / 64];
   __shared__ float sh_lse, sh_mask_text;
   __shared__ float bv[LP_THREADS / 64];
   __shared__ int bi[LP_THREADS / 64];
@@ -379,7 +494,7 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   const int V = gp.V, tb = gp.ts_begin;
   const float NEG = -INFINITY;
 
-  // ---- sparse rules that touch a few ids (done by single threads, then a barrier) ----
+  // ---- sparse rules that touch a few ids (in HBM, before the row is pulled into registers) ----
   if (gp.rep_pen != 1.0f && n > 0) {
     for (int i = tid; i < n; i += LP_THREADS) {
       const int t = hist[i];
@@ -414,30 +529,36 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
       if (hist[i] >= tb) { last_seen = hist[i]; break; }
     if (last_seen >= 0) ts_bound = (last_ts && !penult_ts) ? last_seen : last_seen + 1;
   }
-  // ---- pass 1: element-wise masks + (max, sumexp) over text ids and over timestamp ids ----
+  // ---- pass 1: load the row once, element-wise masks, (max, sumexp) over text / timestamp ids ----
+  float val[LP_NV];
   PairMS pt = {NEG, 0.f}, ps = {NEG, 0.f};
-  for (int v = tid; v < V; v += LP_THREADS) {
-    float x = lg[v];
-    bool kill = sup_mask[v] != 0;
-    if (n == 0 && gp.suppress_blank) {
-      for (int q = 0; q < gp.n_sup_begin; ++q) kill |= (v == gp.sup_begin[q]);
-    }
-    if (n < gp.min_new && v == gp.eot) kill = true;
-    if (gp.with_ts) {
-      if (v == gp.no_ts) kill = true;
-      if (last_ts) {
-        if (penult_ts) { if (v >= tb) kill = true; }
-        else { if (v < gp.eot) kill = true; }
+#pragma unroll
+  for (int i = 0; i < LP_NV; ++i) {
+    const int v = tid + i * LP_THREADS;
+    float x = NEG;
+    if (v < V) {
+      x = lg[v];
+      bool kill = sup_mask[v] != 0;
+      if (n == 0 && gp.suppress_blank) {
+        for (int q = 0; q < gp.n_sup_begin; ++q) kill |= (v == gp.sup_begin[q]);
       }
-      if (v >= tb && v < ts_bound) kill = true;
-      if (n == 0) {
-        if (v < tb) kill = true;
-        if (gp.mits >= 0 && v > tb + gp.mits) kill = true;
+      if (n < gp.min_new && v == gp.eot) kill = true;
+      if (gp.with_ts) {
+        if (v == gp.no_ts) kill = true;
+        if (last_ts) {
+          if (penult_ts) { if (v >= tb) kill = true; }
+          else { if (v < gp.eot) kill = true; }
+        }
+        if (v >= tb && v < ts_bound) kill = true;
+        if (n == 0) {
+          if (v < tb) kill = true;
+          if (gp.mits >= 0 && v > tb + gp.mits) kill = true;
+        }
       }
+      if (kill) x = NEG;
+      if (v < tb) pt = pair_add(pt, x); else ps = pair_add(ps, x);
     }
-    if (kill) x = NEG;
-    lg[v] = x;
-    if (v < tb) pt = pair_add(pt, x); else ps = pair_add(ps, x);
+    val[i] = x;
   }
   pt = pair_wave(pt);
   ps = pair_wave(ps);
@@ -446,38 +567,35 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   if (tid == 0) {
     PairMS a = red_t[0], b = red_s[0];
     for (int i = 1; i < LP_THREADS / 64; ++i) { a = pair_merge(a, red_t[i]); b = pair_merge(b, red_s[i]); }
-    const float lse_t = a.m == NEG ? NEG : a.m + __logf(a.s);
     const float lse_s = b.m == NEG ? NEG : b.m + __logf(b.s);
     const PairMS all = pair_merge(a, b);
     float lse = all.m == NEG ? NEG : all.m + __logf(all.s);
     float mask_text = 0.f;
-    // rule (e): if logsumexp(timestamps) > max(text) (in log-prob space; the common lse cancels)
+    // rule (e): if logsumexp(timestamps) > max(text) (in log-prob space the common lse cancels)
     if (gp.with_ts && lse_s > a.m) { mask_text = 1.f; lse = lse_s; }
-    (void)lse_t;
     sh_lse = lse;
     sh_mask_text = mask_text;
   }
   __syncthreads();
   const float lse = sh_lse;
   const bool mask_text = sh_mask_text != 0.f;
-  // ---- pass 2: log-probs in place, per-thread best candidate ----
-  const float cum = cum2[(size_t)cur * gp.R + r];
-  float best_v = NEG;
-  int best_i = 0x7fffffff;
-  for (int v = tid; v < V; v += LP_THREADS) {
-    float x = lg[v];
+  // ---- pass 2 (registers): log-probs ----
+#pragma unroll
+  for (int i = 0; i < LP_NV; ++i) {
+    const int v = tid + i * LP_THREADS;
+    float x = val[i];
     if (mask_text && v < tb) x = NEG;
-    x = (x == NEG) ? NEG : x - lse;
-    lg[v] = x;
-    if (x > best_v) { best_v = x; best_i = v; }  // ascending v: ties keep the lowest index
+    val[i] = (x == NEG) ? NEG : x - lse;
   }
-  // ---- top-C selection: C rounds of block arg-max; only the winner's owner rescans ----
+  // ---- top-C of cum + logp: C rounds of block arg-max (value desc, index asc) ----
+  const float cum = cum2[(size_t)cur * gp.R + r];
   const int C = 2 * gp.K;
-  float lim_v = INFINITY;
-  int lim_i = -1;  // last taken (value, index): candidates must come strictly after it
   for (int cidx = 0; cidx < C; ++cidx) {
-    float v = best_v;
-    int i = best_i;
+    float v = NEG;
+    int i = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < LP_NV; ++q)
+      if (val[q] > v) { v = val[q]; i = tid + q * LP_THREADS; }  // ascending index: ties keep the lowest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(v, o, 64);
@@ -497,19 +615,12 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
       cand_tok[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? 0 : wi;
     }
     __syncthreads();
-    lim_v = win_v;
-    lim_i = win_i;
-    if (best_i == lim_i && lim_i != 0x7fffffff) {
-      // this thread owned the winner: find its next best element after (lim_v, lim_i)
-      best_v = NEG;
-      best_i = 0x7fffffff;
-      for (int vv = tid; vv < V; vv += LP_THREADS) {
-        const float x = lg[vv];
-        const bool after = (x < lim_v) || (x == lim_v && vv > lim_i);
-        if (after && x > best_v && x != NEG) { best_v = x; best_i = vv; }
-      }
+    const int wi = win_i;
+    if (wi != 0x7fffffff && (wi & (LP_THREADS - 1)) == tid) {
+#pragma unroll
+      for (int q = 0; q < LP_NV; ++q)
+        if (tid + q * LP_THREADS == wi) val[q] = NEG;
     }
-    __syncthreads();
   }
 }
 
@@ -701,31 +812,60 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
   dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, d, d_step, pos_fixed, P);
 }
 
-template <bool F32>
-static int gemm_dispatch(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias,
-                         const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act) {
-  const int grid = (N + 15) / 16;
-  const int mt = (R + 15) / 16;
-#define GO(MT) dec_gemm_kernel<MT, F32><<<grid, 256, 0, st>>>(x, ldx, W, bias, res, ldr, out, ldo, R, N, K, act)
+template <int MT, int NTW, int CH, bool LNF, bool F32>
+static void gemm_go(hipStream_t st, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+                    const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
+                    int K, int act) {
+  const size_t lds = (size_t)(4 * MT * NTW * 256 + 4 * MT * 16 * 2) * sizeof(float);
+  static bool attr_set = false;  // one flag per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MT, NTW, CH, LNF, F32>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dec_gemm_kernel<MT, NTW, CH, LNF, F32><<<grid, 256, lds, st>>>(x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K,
+                                                              act);
+}
+
+template <int NTW, int CH, bool LNF, bool F32>
+static int gemm_mt(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+                   const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
+                   int K, int act) {
+#define GO(MT) gemm_go<MT, NTW, CH, LNF, F32>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act)
   switch (mt) {
     case 1: GO(1); break;
     case 2: GO(2); break;
     case 3: GO(3); break;
     case 4: GO(4); break;
     case 5: GO(5); break;
-    case 6: GO(6); break;
-    case 7: case 8: GO(8); break;
     default: return -1;
   }
 #undef GO
   return 0;
 }
 
-int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const half_t* res,
-                    int ldr, void* out, int ldo, int R, int N, int K, int act, bool out_f32) {
-  if (K % 128 != 0 || R < 1 || R > 128) return -1;
-  return out_f32 ? gemm_dispatch<true>(st, x, ldx, W, bias, res, ldr, out, ldo, R, N, K, act)
-                 : gemm_dispatch<false>(st, x, ldx, W, bias, res, ldr, out, ldo, R, N, K, act);
+// x [R][ldx] fp16 (raw residual stream when s1/cf are given = LayerNorm folded), W [N][K] fp16.
+int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
+                    const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
+                    bool out_f32) {
+  if (K % 128 != 0 || R < 1 || R > 80) return -1;
+  const int mt = (R + 15) / 16;
+  const bool lnf = s1 != nullptr;
+  // columns per workgroup: keep the grid near one wave of workgroups over the 256 CUs
+  const int ntw = (N <= 4096) ? 1 : (N <= 8192 ? 2 : 4);
+  const int grid = (N + 16 * ntw - 1) / (16 * ntw);
+  if (out_f32) {
+    if (!lnf) return -1;
+    if (ntw == 4) return gemm_mt<4, 2, true, true>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+    if (ntw == 2) return gemm_mt<2, 3, true, true>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+    return gemm_mt<1, 3, true, true>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+  }
+  if (lnf) {
+    if (ntw >= 2) return gemm_mt<2, 3, true, false>(st, mt, (N + 31) / 32, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+    return gemm_mt<1, 3, true, false>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+  }
+  if (ntw >= 2) return gemm_mt<2, 3, false, false>(st, mt, (N + 31) / 32, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+  return gemm_mt<1, 3, false, false>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
 }
 
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,

@@ -66,7 +66,7 @@ int gen_workspace_create(Model* m) {
   g->NT = c.n_text_ctx;
   const size_t B = g->B, R = g->R, d = c.d_model, T = c.n_audio_ctx, L = c.n_dec_layers, NT = g->NT;
   const size_t Rg = std::max<size_t>(R, B);
-  FW_CHECK_ARG(R <= 128, "max_batch * max_beam must be <= 128 (got %zu)", R);
+  FW_CHECK_ARG(R <= 80, "max_batch * max_beam must be <= 80 (got %zu)", R);
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
   A(g->ck, L * B * T * d);
@@ -178,9 +178,9 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const half_t* ck = g->ck + (size_t)l * g->B * T * d;
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * m->t_pad;
     {
-      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      fwk::launch_layernorm(st, g->x, L.ln1.g, L.ln1.b, g->xn, rows, d);
-      DG(fwd::launch_dec_gemm(st, g->xn, d, L.qkv.w, L.qkv.b, nullptr, 0, g->qkv, 3 * d, rows, 3 * d, d, 0, false));
+      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
+      DG(fwd::launch_dec_gemm(st, g->x, d, L.qkv.w, nullptr, L.qkv.s1, L.qkv.cf, nullptr, 0, g->qkv, 3 * d, rows,
+                              3 * d, d, 0, false));
     }
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0);
@@ -189,17 +189,16 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
-      DG(fwd::launch_dec_gemm(st, g->att, d, L.out.w, L.out.b, g->x, d, g->x, d, rows, d, d, 0, false));
-      fwk::launch_layernorm(st, g->x, L.ln2.g, L.ln2.b, g->xn, rows, d);
-      DG(fwd::launch_dec_gemm(st, g->xn, d, L.cq.w, L.cq.b, nullptr, 0, g->qc, d, rows, d, d, 0, false));
+      DG(fwd::launch_dec_gemm(st, g->att, d, L.out.w, L.out.b, nullptr, nullptr, g->x, d, g->x, d, rows, d, d, 0,
+                              false));
+      DG(fwd::launch_dec_gemm(st, g->x, d, L.cq.w, nullptr, L.cq.s1, L.cq.cf, nullptr, 0, g->qc, d, rows, d, d, 0,
+                              false));
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0);
       const int off = s.sel_layer_off[l], n = s.sel_layer_off[l + 1] - off;
       fwd::launch_cross_probs(st, g->qc, d, ck, T, s.sel_heads_dev + off, n, s.n_sel_total,
                               s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
-      // note: probs layout [b][sel][tok][T]; the per-layer slice starts at sel offset `off`
-      (void)n;
     }
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * s.B * (double)T * d);
@@ -207,17 +206,18 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 9.0 * d * d, 2.0 * 9.0 * d * d);
-      DG(fwd::launch_dec_gemm(st, g->att, d, L.cout.w, L.cout.b, g->x, d, g->x, d, rows, d, d, 0, false));
-      fwk::launch_layernorm(st, g->x, L.ln3.g, L.ln3.b, g->xn, rows, d);
-      DG(fwd::launch_dec_gemm(st, g->xn, d, L.ffn1.w, L.ffn1.b, nullptr, 0, g->ffn, 4 * d, rows, 4 * d, d, 1, false));
-      DG(fwd::launch_dec_gemm(st, g->ffn, 4 * d, L.ffn2.w, L.ffn2.b, g->x, d, g->x, d, rows, d, 4 * d, 0, false));
+      DG(fwd::launch_dec_gemm(st, g->att, d, L.cout.w, L.cout.b, nullptr, nullptr, g->x, d, g->x, d, rows, d, d, 0,
+                              false));
+      DG(fwd::launch_dec_gemm(st, g->x, d, L.ffn1.w, nullptr, L.ffn1.s1, L.ffn1.cf, nullptr, 0, g->ffn, 4 * d, rows,
+                              4 * d, d, 1, false));
+      DG(fwd::launch_dec_gemm(st, g->ffn, 4 * d, L.ffn2.w, L.ffn2.b, nullptr, nullptr, g->x, d, g->x, d, rows, d,
+                              4 * d, 0, false));
     }
   }
   if (s.need_logits || s.beam_tail) {
     ProfScope ps(m, PF_DEC_LOGITS, 2.0 * rows * (double)c.n_vocab * d, 2.0 * c.n_vocab * d);
-    fwk::launch_layernorm(st, g->x, m->dec_ln.g, m->dec_ln.b, g->xn, rows, d);
-    DG(fwd::launch_dec_gemm(st, g->xn, d, m->tok_emb, nullptr, nullptr, 0, g->logits, c.n_vocab, rows, c.n_vocab, d,
-                            0, true));
+    DG(fwd::launch_dec_gemm(st, g->x, d, m->logits.w, nullptr, m->logits.s1, m->logits.cf, nullptr, 0, g->logits,
+                            c.n_vocab, rows, c.n_vocab, d, 0, true));
   }
   if (s.nospeech_rowmul > 0) {
     ProfScope ps(m, PF_DEC_MISC, 0, 0);

@@ -61,12 +61,15 @@ struct LinearW {           // y = x W^T + b ; W [N][K] fp16 (or int8 + per-row s
   const half_t* b = nullptr;
   const int8_t* wq = nullptr;    // int8 weights [N][K]           (int8_float16 only)
   const float* wscale = nullptr; // dequant scale per output row  (int8_float16 only)
+  // LayerNorm-folded form (decoder): w = W.g, y = rstd*(w x - mu*s1) + cf   (engine.hip add_folded)
+  const float* s1 = nullptr;
+  const float* cf = nullptr;
   int N = 0, K = 0;
 };
 struct LNW { const half_t* g = nullptr; const half_t* b = nullptr; };
 
 struct EncLayerW { LNW ln1, ln2; LinearW qk, v, out, ffn1, ffn2; };
-struct DecLayerW { LNW ln1, ln2, ln3; LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };
+struct DecLayerW { LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };  // qkv, cq, ffn1: LN-folded
 
 enum ProfFamily {
   PF_LOGMEL = 0, PF_ENC_GEMM, PF_ENC_ATTN, PF_ENC_LN, PF_CROSS_KV_GEMM,
@@ -108,7 +111,7 @@ struct Model {
   const half_t* tok_emb = nullptr;  // [V][d]
   const half_t* dec_pos = nullptr;  // [n_text_ctx][d]
   std::vector<DecLayerW> dec;
-  LNW dec_ln;
+  LinearW logits;  // final LN folded into the tied-embedding projection
 
   // log-mel constants
   float* lm_consts = nullptr;  // cos table [400] + hann [400]

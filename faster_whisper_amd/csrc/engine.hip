@@ -91,8 +91,18 @@ struct PackItem {
   std::string name;
   int ndim;
   int64_t dims[4];
-  std::vector<uint16_t> data;  // fp16 payload
+  std::vector<uint16_t> data;  // fp16 payload (dtype 1)
+  std::vector<float> fdata;    // fp32 payload (dtype 0)
+  int dtype = 1;
+  const void* bytes() const { return dtype == 1 ? (const void*)data.data() : (const void*)fdata.data(); }
+  int64_t nbytes() const { return dtype == 1 ? (int64_t)data.size() * 2 : (int64_t)fdata.size() * 4; }
 };
+
+static inline float f16_bits_to_f32(uint16_t u) {
+  half_t h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
 
 static const fw_weight* find_w(const fw_weight* w, int n, const std::string& name) {
   for (int i = 0; i < n; ++i)
@@ -193,6 +203,48 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     items.push_back(std::move(it));
     return add_plain(name + ".b", {cout});
   };
+  // LayerNorm folded into the consuming linear (decoder rows are few, so the LN kernel would be
+  // pure launch overhead):   y = W (g*(x-mu)*rstd + b) + bias
+  //                            = rstd * ( (W.g) x - mu * s1 ) + cf,   s1 = rowsum(W.g), cf = W b + bias
+  // emits  <out>.wf [N][K] fp16 (W.g),  <out>.s1 [N] f32,  <out>.cf [N] f32
+  auto add_folded = [&](const std::string& out, const std::string& wname, const std::string& bname,
+                        const std::string& gname, const std::string& lbname, int N, int K) -> int {
+    const fw_weight* W = find_w(w, nw, wname);
+    const fw_weight* G = find_w(w, nw, gname);
+    const fw_weight* LB = find_w(w, nw, lbname);
+    const fw_weight* Bi = bname.empty() ? nullptr : find_w(w, nw, bname);
+    int rc = expect_shape(W, wname, {N, K});
+    if (rc) return rc;
+    if ((rc = expect_shape(G, gname, {K}))) return rc;
+    if ((rc = expect_shape(LB, lbname, {K}))) return rc;
+    if (!bname.empty() && (rc = expect_shape(Bi, bname, {N}))) return rc;
+    std::vector<float> g(K), lb(K);
+    for (int k = 0; k < K; ++k) {
+      g[k] = f16_bits_to_f32(f32_to_f16_bits(w_at(G, k)));
+      lb[k] = f16_bits_to_f32(f32_to_f16_bits(w_at(LB, k)));
+    }
+    PackItem wf, s1, cf;
+    wf.name = out + ".wf"; wf.ndim = 2; wf.dims[0] = N; wf.dims[1] = K; wf.dims[2] = wf.dims[3] = 1;
+    wf.data.resize((size_t)N * K);
+    s1.name = out + ".s1"; s1.ndim = 1; s1.dims[0] = N; s1.dims[1] = s1.dims[2] = s1.dims[3] = 1; s1.dtype = 0;
+    cf.name = out + ".cf"; cf.ndim = 1; cf.dims[0] = N; cf.dims[1] = cf.dims[2] = cf.dims[3] = 1; cf.dtype = 0;
+    s1.fdata.resize(N); cf.fdata.resize(N);
+    for (int n = 0; n < N; ++n) {
+      double a1 = 0.0, ac = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const float wv = f16_bits_to_f32(f32_to_f16_bits(w_at(W, (int64_t)n * K + k)));
+        const uint16_t wg = f32_to_f16_bits(wv * g[k]);
+        wf.data[(size_t)n * K + k] = wg;
+        a1 += (double)f16_bits_to_f32(wg);
+        ac += (double)wv * (double)lb[k];
+      }
+      if (Bi) ac += (double)f16_bits_to_f32(f32_to_f16_bits(w_at(Bi, n)));
+      s1.fdata[n] = (float)a1;
+      cf.fdata[n] = (float)ac;
+    }
+    items.push_back(std::move(wf)); items.push_back(std::move(s1)); items.push_back(std::move(cf));
+    return FW_OK;
+  };
   int rc;
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
   TRY(add_conv("enc.conv1", d, nm, c_pad));
@@ -213,18 +265,16 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   TRY(add_plain("dec.pos", {cfg->n_text_ctx, d}));
   for (int i = 0; i < cfg->n_dec_layers; ++i) {
     auto nmf = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
-    TRY(add_plain(nmf("ln1.g"), {d})); TRY(add_plain(nmf("ln1.b"), {d}));
-    TRY(add_plain(nmf("self.qkv.w"), {3 * d, d})); TRY(add_plain(nmf("self.qkv.b"), {3 * d}));
+    // the three LayerNorms of a decoder block are folded into the linear that consumes them
+    TRY(add_folded(nmf("self.qkv"), nmf("self.qkv.w"), nmf("self.qkv.b"), nmf("ln1.g"), nmf("ln1.b"), 3 * d, d));
     TRY(add_plain(nmf("self.out.w"), {d, d})); TRY(add_plain(nmf("self.out.b"), {d}));
-    TRY(add_plain(nmf("ln2.g"), {d})); TRY(add_plain(nmf("ln2.b"), {d}));
-    TRY(add_plain(nmf("cross.q.w"), {d, d})); TRY(add_plain(nmf("cross.q.b"), {d}));
+    TRY(add_folded(nmf("cross.q"), nmf("cross.q.w"), nmf("cross.q.b"), nmf("ln2.g"), nmf("ln2.b"), d, d));
     TRY(add_plain(nmf("cross.kv.w"), {2 * d, d})); TRY(add_plain(nmf("cross.kv.b"), {2 * d}));
     TRY(add_plain(nmf("cross.out.w"), {d, d})); TRY(add_plain(nmf("cross.out.b"), {d}));
-    TRY(add_plain(nmf("ln3.g"), {d})); TRY(add_plain(nmf("ln3.b"), {d}));
-    TRY(add_plain(nmf("ffn1.w"), {4 * d, d})); TRY(add_plain(nmf("ffn1.b"), {4 * d}));
+    TRY(add_folded(nmf("ffn1"), nmf("ffn1.w"), nmf("ffn1.b"), nmf("ln3.g"), nmf("ln3.b"), 4 * d, d));
     TRY(add_plain(nmf("ffn2.w"), {d, 4 * d})); TRY(add_plain(nmf("ffn2.b"), {d}));
   }
-  TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
+  TRY(add_folded("dec.logits", "dec.tok_emb", "", "dec.ln.g", "dec.ln.b", cfg->n_vocab, d));
 #undef TRY
 
   const int64_t hdr = (int64_t)sizeof(BlobHeader) + (int64_t)items.size() * sizeof(BlobEntry);
@@ -234,11 +284,11 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     BlobEntry& e = entries[i];
     memset(&e, 0, sizeof(e));
     snprintf(e.name, sizeof(e.name), "%s", items[i].name.c_str());
-    e.dtype = 1;
+    e.dtype = items[i].dtype;
     e.ndim = items[i].ndim;
     for (int k = 0; k < 4; ++k) e.dims[k] = items[i].dims[k];
     e.offset = off;
-    e.nbytes = (int64_t)items[i].data.size() * 2;
+    e.nbytes = items[i].nbytes();
     off = (off + e.nbytes + 255) / 256 * 256;
   }
   blob.assign((size_t)off, 0);
@@ -253,7 +303,7 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   memcpy(blob.data(), &h, sizeof(h));
   memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
   for (size_t i = 0; i < items.size(); ++i)
-    memcpy(blob.data() + entries[i].offset, items[i].data.data(), (size_t)entries[i].nbytes);
+    memcpy(blob.data() + entries[i].offset, items[i].bytes(), (size_t)entries[i].nbytes);
   return FW_OK;
 }
 
@@ -344,8 +394,8 @@ static int bind_weights(Model* m) {
     const half_t *qkvw, *qkvb;
     NEED(nm("ln1.g"), &L.ln1.g); NEED(nm("ln1.b"), &L.ln1.b);
     NEED(nm("attn.qkv.w"), &qkvw); NEED(nm("attn.qkv.b"), &qkvb);
-    L.qk = LinearW{qkvw, qkvb, nullptr, nullptr, 2 * d, d};
-    L.v = LinearW{qkvw + (size_t)2 * d * d, qkvb + 2 * d, nullptr, nullptr, d, d};
+    L.qk = LinearW{qkvw, qkvb, nullptr, nullptr, nullptr, nullptr, 2 * d, d};
+    L.v = LinearW{qkvw + (size_t)2 * d * d, qkvb + 2 * d, nullptr, nullptr, nullptr, nullptr, d, d};
     NEED(nm("attn.out.w"), &L.out.w); NEED(nm("attn.out.b"), &L.out.b); L.out.N = d; L.out.K = d;
     NEED(nm("ln2.g"), &L.ln2.g); NEED(nm("ln2.b"), &L.ln2.b);
     NEED(nm("ffn1.w"), &L.ffn1.w); NEED(nm("ffn1.b"), &L.ffn1.b); L.ffn1.N = 4 * d; L.ffn1.K = d;
@@ -354,24 +404,37 @@ static int bind_weights(Model* m) {
   NEED("enc.ln_post.g", &m->enc_ln_post.g); NEED("enc.ln_post.b", &m->enc_ln_post.b);
   NEED("dec.tok_emb", &m->tok_emb); NEED("dec.pos", &m->dec_pos);
   m->dec.resize(c.n_dec_layers);
+  auto need_f = [&](const std::string& n, const float** out) -> int {
+    *out = reinterpret_cast<const float*>(tptr(m, n));
+    if (!*out) {
+      set_error("weight blob lacks tensor '%s'", n.c_str());
+      return FW_EINVAL;
+    }
+    return FW_OK;
+  };
+  auto folded = [&](const std::string& base, LinearW* L, int N, int K) -> int {
+    int r;
+    if ((r = need(base + ".wf", &L->w))) return r;
+    if ((r = need_f(base + ".s1", &L->s1))) return r;
+    if ((r = need_f(base + ".cf", &L->cf))) return r;
+    L->b = nullptr; L->N = N; L->K = K;
+    return FW_OK;
+  };
   for (int i = 0; i < c.n_dec_layers; ++i) {
     DecLayerW& L = m->dec[i];
     auto nm = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
     const half_t *kvw, *kvb;
-    NEED(nm("ln1.g"), &L.ln1.g); NEED(nm("ln1.b"), &L.ln1.b);
-    NEED(nm("self.qkv.w"), &L.qkv.w); NEED(nm("self.qkv.b"), &L.qkv.b); L.qkv.N = 3 * d; L.qkv.K = d;
+    if ((rc = folded(nm("self.qkv"), &L.qkv, 3 * d, d))) return rc;
     NEED(nm("self.out.w"), &L.out.w); NEED(nm("self.out.b"), &L.out.b); L.out.N = d; L.out.K = d;
-    NEED(nm("ln2.g"), &L.ln2.g); NEED(nm("ln2.b"), &L.ln2.b);
-    NEED(nm("cross.q.w"), &L.cq.w); NEED(nm("cross.q.b"), &L.cq.b); L.cq.N = d; L.cq.K = d;
+    if ((rc = folded(nm("cross.q"), &L.cq, d, d))) return rc;
     NEED(nm("cross.kv.w"), &kvw); NEED(nm("cross.kv.b"), &kvb);
-    L.ck = LinearW{kvw, kvb, nullptr, nullptr, d, d};
-    L.cv = LinearW{kvw + (size_t)d * d, kvb + d, nullptr, nullptr, d, d};
+    L.ck = LinearW{kvw, kvb, nullptr, nullptr, nullptr, nullptr, d, d};
+    L.cv = LinearW{kvw + (size_t)d * d, kvb + d, nullptr, nullptr, nullptr, nullptr, d, d};
     NEED(nm("cross.out.w"), &L.cout.w); NEED(nm("cross.out.b"), &L.cout.b); L.cout.N = d; L.cout.K = d;
-    NEED(nm("ln3.g"), &L.ln3.g); NEED(nm("ln3.b"), &L.ln3.b);
-    NEED(nm("ffn1.w"), &L.ffn1.w); NEED(nm("ffn1.b"), &L.ffn1.b); L.ffn1.N = 4 * d; L.ffn1.K = d;
+    if ((rc = folded(nm("ffn1"), &L.ffn1, 4 * d, d))) return rc;
     NEED(nm("ffn2.w"), &L.ffn2.w); NEED(nm("ffn2.b"), &L.ffn2.b); L.ffn2.N = d; L.ffn2.K = 4 * d;
   }
-  NEED("dec.ln.g", &m->dec_ln.g); NEED("dec.ln.b", &m->dec_ln.b);
+  if ((rc = folded("dec.logits", &m->logits, c.n_vocab, d))) return rc;
 #undef NEED
   return FW_OK;
 }
@@ -1005,7 +1068,7 @@ int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* 
   if (bias && (rc = upload_f16(m, bias, N, &dB))) return rc;
   if (residual && (rc = upload_f16(m, residual, (size_t)M * N, &dR))) return rc;
   if ((rc = dev_alloc_t(&dC, (size_t)M * N))) return rc;
-  LinearW L{dW, dB, nullptr, nullptr, N, K};
+  LinearW L{dW, dB, nullptr, nullptr, nullptr, nullptr, N, K};
   if (act_gelu >= 2) {
     // transposed-output mode: out is [N][M]
     rc = run_linear(m, L, dA, K, 0, dC, M, 0, nullptr, 0, 0, M, 1, act_gelu - 2, true);

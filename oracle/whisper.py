@@ -97,8 +97,9 @@ class OracleWhisper:
         return (o, p) if return_probs else o
 
     # ------------------------------------------------------------------ encoder
-    def encode(self, features: np.ndarray) -> np.ndarray:
-        """features float32 [B, n_mels, 3000] -> [B, 1500, d]"""
+    def encode(self, features: np.ndarray, n_layers: Optional[int] = None) -> np.ndarray:
+        """features float32 [B, n_mels, 3000] -> [B, 1500, d]
+        n_layers: run only the first n transformer blocks (bench.py's bounded CPU-baseline sample)"""
         with torch.no_grad():
             x = self._r(_t(features))
             x = self._r(torch.nn.functional.gelu(
@@ -106,7 +107,7 @@ class OracleWhisper:
             x = torch.nn.functional.gelu(
                 torch.nn.functional.conv1d(x, self.w["enc.conv2.w"], self.w["enc.conv2.b"], stride=2, padding=1))
             x = self._r(x.transpose(1, 2) + self.w["enc.pos"])
-            for i in range(self.cfg.n_enc_layers):
+            for i in range(self.cfg.n_enc_layers if n_layers is None else n_layers):
                 p = f"enc.{i}."
                 xn = self._ln(x, p + "ln1")
                 qkv = self._lin(xn, p + "attn.qkv")
