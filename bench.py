@@ -42,12 +42,14 @@ def synth_chunks(n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=100)
+    ap.add_argument("--workers", type=int, default=4,
+                    help="batches kept in flight per GPU (worker replicas sharing the weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
@@ -76,13 +78,13 @@ def main():
             blob = pack_blob(cfg, weights)
         dev_blob = broadcast_blob(blob, rank, local_rank)           # RCCL broadcast over xGMI
         model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
-                        max_batch_size=args.batch, max_beam_size=args.beam,
+                        max_batch_size=args.batch, max_beam_size=args.beam, inter_threads=args.workers,
                         blob_dev=(dev_blob.data_ptr(), dev_blob.numel()))
     else:
         weights = synthetic_weights(cfg, seed=1234)
         model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
                         files={"config": cfg, "weights": weights}, max_batch_size=args.batch,
-                        max_beam_size=args.beam)
+                        max_beam_size=args.beam, inter_threads=args.workers)
     load_s = time.time() - t0
 
     chunks = synth_chunks(args.batch, seed=1000 + rank)
@@ -96,22 +98,43 @@ def main():
 
     def step():
         enc = model.encode_pcm_staged(staged)
-        res = model.generate(enc, [prompt] * args.batch, **gen_kw)
-        if world > 1:
-            gather_results(res, L, rank, world, local_rank)
-        return res
+        return model.generate(enc, [prompt] * args.batch, **gen_kw)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        model._lib.fw_synchronize(model._replicas[0].handle)
+        for r in model._replicas:
+            model._lib.fw_synchronize(r.handle)
 
-    for _ in range(args.warmup):
-        res = step()
+    # W host threads, one worker replica (stream + workspaces, shared weights) each: the batches of
+    # a long recording are independent, so several are kept in flight on the GPU at once.
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    W = max(1, args.workers)
+    pool = ThreadPoolExecutor(max_workers=W)
+    sync = threading.Barrier(W)
+
+    def warm(_):
+        sync.wait()                      # every pool thread takes exactly one of these tasks
+        for _ in range(max(1, args.warmup)):
+            r = step()
+        return r
+
+    def run_steps(n):
+        futs = [pool.submit(step) for _ in range(n)]
+        outs = []
+        for f in futs:                   # results come back in submission order = chunk order
+            r = f.result()
+            if world > 1:
+                gather_results(r, L, rank, world, local_rank)
+            outs.append(r)
+        return outs
+
+    if args.warmup > 0:
+        res = list(pool.map(warm, range(W)))[-1]
     barrier()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps)[-1]
     barrier()
     elapsed = time.perf_counter() - t1
     if world > 1:
@@ -131,16 +154,17 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{args.model} fp16 BatchedInferencePipeline hot path: {args.batch} x 30 s chunks/step, "
                                f"beam_size={args.beam}, {L} new tokens/chunk (fixed), PCM resident in HBM",
-                   "global_batch": args.batch * world, "new_tokens": L, "model_load_s": round(load_s, 1)},
+                   "global_batch": args.batch * world, "new_tokens": L, "batches_in_flight_per_gpu": W, "model_load_s": round(load_s, 1)},
     }
 
     if rank == 0:
         # ---- roofline of the dominant kernel family: profiled pass (HIP events on the engine stream) ----
         if not args.no_profile_pass:
-            model.profile(True)
+            ridx = model._replicas.index(model._replica_for(None))   # the main thread's worker
+            model.profile(True, replica=ridx)
             step()
-            rep = model.profile_report()
-            model.profile(False)
+            rep = model.profile_report(replica=ridx)
+            model.profile(False, replica=ridx)
             tot = sum(v["ms"] for v in rep.values())
             name, dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
             if name in MFMA_FAMILIES:

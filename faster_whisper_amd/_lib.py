@@ -55,7 +55,7 @@ class FwGenOpts(C.Structure):
 # every symbol include/fwamd.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [
     "fw_last_error", "fw_abi_version", "fw_device_count",
-    "fw_model_create", "fw_model_free", "fw_model_info", "fw_model_create_from_blob_dev",
+    "fw_model_create", "fw_model_free", "fw_model_info", "fw_model_blob", "fw_model_create_from_blob_dev",
     "fw_pack_blob_size", "fw_pack_blob_copy", "fw_pack_blob_free",
     "fw_logmel", "fw_logmel_full",
     "fw_encode", "fw_encode_pcm", "fw_encode_pcm_dev", "fw_tensor_shape", "fw_tensor_to_host",
@@ -92,6 +92,7 @@ def load():
     lib.fw_model_free.argtypes = [vp]
     lib.fw_model_free.restype = None
     lib.fw_model_info.argtypes = [vp, C.POINTER(FwConfig), i32p, i32p, i32p, i32p]
+    lib.fw_model_blob.argtypes = [vp, C.POINTER(vp), i64p]
     lib.fw_model_create_from_blob_dev.argtypes = [C.POINTER(FwConfig), vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
     lib.fw_pack_blob_size.argtypes = [C.POINTER(FwConfig), C.POINTER(FwWeight), i32, i32, i64p, C.POINTER(vp)]
     lib.fw_pack_blob_copy.argtypes = [vp, vp, i64]

@@ -228,12 +228,22 @@ class Whisper:
         self._cfg = cfg
         idx = [device_index] if isinstance(device_index, int) else list(device_index)
         self._device_index = idx
-        self._replicas = [_Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev) for i in idx]
-        self._pool: "queue.Queue[_Replica]" = queue.Queue()
-        for r in self._replicas:
-            for _ in range(max(1, inter_threads)):
-                self._pool.put(r)
         self._lib = _lib.load()
+        # one replica per (device, worker): the `inter_threads` workers of a device share ONE copy of the
+        # weights in HBM and own a stream + workspaces each (CTranslate2 replica pool semantics,
+        # transcribe.py:645-657), so concurrent transcribe() threads overlap on the GPU
+        self._replicas = []
+        for i in idx:
+            primary = _Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev)
+            self._replicas.append(primary)
+            if inter_threads > 1:
+                p, n = C.c_void_p(), C.c_int64()
+                _lib.check(self._lib.fw_model_blob(primary.handle, C.byref(p), C.byref(n)))
+                for _ in range(inter_threads - 1):
+                    self._replicas.append(_Replica(cfg, None, ct, i, max_batch_size, max_beam_size,
+                                                   (p.value, n.value)))
+        self._rr = itertools.count()
+        self._tls = threading.local()
 
     # ---- properties read by the reference host code -------------------------------------
     @property
@@ -267,8 +277,12 @@ class Whisper:
     def _replica_for(self, features: Optional[StorageView]) -> _Replica:
         if features is not None and features._owner is not None:
             return features._owner
-        r = self._pool.get()
-        self._pool.put(r)
+        # thread affinity: a host thread keeps the replica it was first given (round-robin), so W
+        # threads on W replicas never contend and an encoder output stays with its worker
+        r = getattr(self._tls, "replica", None)
+        if r is None:
+            r = self._replicas[next(self._rr) % len(self._replicas)]
+            self._tls.replica = r
         return r
 
     def _as_encoded(self, features: StorageView) -> StorageView:
@@ -327,7 +341,10 @@ class Whisper:
         _lib.check(self._lib.fw_dev_free(staged["rep"].handle, staged["dev"]))
 
     def encode_pcm_staged(self, staged) -> StorageView:
-        rep = staged["rep"]
+        # the staged PCM lives in HBM of the device: any worker replica of that device may consume it
+        rep = self._replica_for(None)
+        if rep.device_index != staged["rep"].device_index:
+            rep = staged["rep"]
         h = C.c_void_p()
         _lib.check(self._lib.fw_encode_pcm_dev(rep.handle, staged["dev"], _lib.as_i64p(staged["offsets"]),
                                                staged["B"], C.byref(h)))

@@ -136,6 +136,10 @@ struct Model {
 
   GenWorkspace* gen = nullptr;
 
+  // pooled encoder-output buffers ([max_batch][T][d] each)
+  std::mutex pool_mu;
+  std::vector<half_t*> enc_pool;
+
   // profiling
   bool prof_on = false;
   ProfAcc prof[PF_COUNT];

@@ -362,6 +362,8 @@ static int setup_logmel_consts(Model* m) {
 }
 
 // ---------------------------------------------------------------- model construction
+std::mutex& g_models_mu_ref();
+std::vector<Model*>& g_live_models_ref();
 static const half_t* tptr(Model* m, const std::string& name) {
   auto it = m->tensors.find(name);
   return it == m->tensors.end() ? nullptr : reinterpret_cast<const half_t*>(it->second.ptr);
@@ -518,6 +520,10 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
     set_error("device sync after model setup failed: %s", hipGetErrorString(he));
     return fail(FW_ENODEV);
   }
+  {
+    std::lock_guard<std::mutex> lk(g_models_mu_ref());
+    g_live_models_ref().push_back(m);
+  }
   *out = fm;
   return FW_OK;
 }
@@ -618,14 +624,30 @@ static int new_tensor(Model* m, int B, fw_tensor** out) {
   t->impl.T = m->cfg.n_audio_ctx;
   t->impl.D = m->cfg.d_model;
   t->impl.id = next_tensor_id();
-  int rc = dev_alloc_t(&t->impl.data, (size_t)B * t->impl.T * t->impl.D);
-  if (rc) {
-    delete t;
-    return rc;
+  // encoder outputs come from a per-model pool (every buffer holds max_batch rows): hipMalloc/hipFree
+  // synchronise the whole device and would serialise the replicas that share a GPU
+  {
+    std::lock_guard<std::mutex> lk(m->pool_mu);
+    if (!m->enc_pool.empty()) {
+      t->impl.data = m->enc_pool.back();
+      m->enc_pool.pop_back();
+    }
+  }
+  if (!t->impl.data) {
+    int rc = dev_alloc_t(&t->impl.data, (size_t)m->max_batch * t->impl.T * t->impl.D);
+    if (rc) {
+      delete t;
+      return rc;
+    }
   }
   *out = t;
   return FW_OK;
 }
+
+static std::mutex g_models_mu;
+static std::vector<Model*> g_live_models;
+std::mutex& g_models_mu_ref() { return g_models_mu; }
+std::vector<Model*>& g_live_models_ref() { return g_live_models; }
 
 static int ensure_pcm(Model* m, int64_t n) {
   if (n <= m->ws_pcm_cap) return FW_OK;
@@ -774,9 +796,15 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
 void fw_model_free(fw_model* fm) {
   if (!fm) return;
   Model* m = &fm->impl;
+  {
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    g_live_models.erase(std::remove(g_live_models.begin(), g_live_models.end(), m), g_live_models.end());
+  }
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   gen_workspace_free(m);
+  for (half_t* p : m->enc_pool) (void)hipFree(p);
+  m->enc_pool.clear();
   void* ptrs[] = {m->lm_consts, m->lm_filtT, m->ws_pcm, m->ws_offsets, m->ws_raw, m->ws_chunk_max, m->ws_nframes,
                   m->ws_feat32, m->ws_mel_cl, m->ws_conv1, m->ws_x, m->ws_x2, m->ws_xn, m->ws_qk, m->ws_vt,
                   m->ws_att, m->ws_ffn};
@@ -787,6 +815,13 @@ void fw_model_free(fw_model* fm) {
   for (auto e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete fm;
+}
+
+int32_t fw_model_blob(const fw_model* fm, void** blob_dev, int64_t* blob_bytes) {
+  FW_CHECK_ARG(fm && blob_dev && blob_bytes, "null argument");
+  *blob_dev = fm->impl.blob;
+  *blob_bytes = fm->impl.blob_bytes;
+  return FW_OK;
 }
 
 int32_t fw_model_info(const fw_model* fm, fw_config* cfg_out, int32_t* compute_type, int32_t* device_index,
@@ -985,8 +1020,17 @@ int32_t fw_tensor_from_host(fw_model* fm, const float* data, int32_t B, fw_tenso
 
 void fw_tensor_free(fw_tensor* t) {
   if (!t) return;
-  if (t->impl.owner) (void)hipSetDevice(t->impl.owner->device);
-  if (t->impl.data) (void)hipFree(t->impl.data);
+  if (t->impl.data) {
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    Model* m = t->impl.owner;
+    const bool alive = std::find(g_live_models.begin(), g_live_models.end(), m) != g_live_models.end();
+    if (alive) {
+      std::lock_guard<std::mutex> lk2(m->pool_mu);
+      m->enc_pool.push_back(t->impl.data);
+    } else {
+      (void)hipFree(t->impl.data);
+    }
+  }
   delete t;
 }
 

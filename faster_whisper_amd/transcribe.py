@@ -1,0 +1,618 @@
+"""Host-side mirror of the reference's batched transcription API for the hot path.
+
+Mirrors (same names, argument meaning, defaults and error behaviour)
+    faster_whisper/transcribe.py : Word, Segment, TranscriptionOptions, TranscriptionInfo (:31-108),
+        BatchedInferencePipeline.forward / generate_segment_batched / transcribe /
+        _batched_segments_generator (:111-617), WhisperModel.__init__ attributes (:620-722),
+        encode (:1391-1400), get_prompt (:1532-1565), _split_segments_by_timestamps (:1024-1101),
+        find_alignment (:1698-1766), detect_language (:1768-1841), get_suppressed_tokens (:1884-1907),
+        get_compression_ratio (:1879-1881)
+    faster_whisper/audio.py : pad_or_trim (:111-123)
+    faster_whisper/feature_extractor.py : FeatureExtractor (the arithmetic runs on the GPU here)
+but is written for this engine: features are computed on the GPU, the backend is
+`faster_whisper_amd.backend.Whisper`, and `transcribe(..., shard=True)` partitions the chunk
+list over the ranks of a torch.distributed job.
+
+Out of scope for this tier: the sequential seek loop
+(`WhisperModel.transcribe`), Silero VAD, PyAV decoding, the word-timestamp heuristics.  The
+reference's own host code runs unchanged on top of `faster_whisper_amd.ct2_shim` for those.
+"""
+import json
+import logging
+import os
+import zlib
+from dataclasses import dataclass
+from math import ceil
+from typing import Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from .backend import StorageView, Whisper, language_token_strings
+from .config import WhisperConfig
+
+_LOG = logging.getLogger("faster_whisper")
+
+
+@dataclass
+class Word:
+    start: float
+    end: float
+    word: str
+    probability: float
+
+
+@dataclass
+class Segment:
+    id: int
+    seek: int
+    start: float
+    end: float
+    text: str
+    tokens: List[int]
+    avg_logprob: float
+    compression_ratio: float
+    no_speech_prob: float
+    words: Optional[List[Word]]
+    temperature: Optional[float]
+
+
+@dataclass
+class TranscriptionOptions:
+    beam_size: int
+    best_of: int
+    patience: float
+    length_penalty: float
+    repetition_penalty: float
+    no_repeat_ngram_size: int
+    log_prob_threshold: Optional[float]
+    no_speech_threshold: Optional[float]
+    compression_ratio_threshold: Optional[float]
+    condition_on_previous_text: bool
+    prompt_reset_on_temperature: float
+    temperatures: List[float]
+    initial_prompt: Optional[Union[str, Iterable[int]]]
+    prefix: Optional[str]
+    suppress_blank: bool
+    suppress_tokens: Optional[List[int]]
+    without_timestamps: bool
+    max_initial_timestamp: float
+    word_timestamps: bool
+    prepend_punctuations: str
+    append_punctuations: str
+    multilingual: bool
+    max_new_tokens: Optional[int]
+    clip_timestamps: Union[str, List[float]]
+    hallucination_silence_threshold: Optional[float]
+    hotwords: Optional[str]
+
+
+@dataclass
+class TranscriptionInfo:
+    language: str
+    language_probability: float
+    duration: float
+    duration_after_vad: float
+    all_language_probs: Optional[List[Tuple[str, float]]]
+    transcription_options: TranscriptionOptions
+    vad_options: object
+
+
+def pad_or_trim(array: np.ndarray, length: int = 3000, *, axis: int = -1) -> np.ndarray:
+    """trim to `length` frames or right-pad with zeros (audio.py:111-123)"""
+    if array.shape[axis] > length:
+        array = np.take(array, np.arange(length), axis=axis)
+    if array.shape[axis] < length:
+        pad = [(0, 0)] * array.ndim
+        pad[axis] = (0, length - array.shape[axis])
+        array = np.pad(array, pad)
+    return array
+
+
+def get_compression_ratio(text: str) -> float:
+    raw = text.encode("utf-8")
+    return len(raw) / len(zlib.compress(raw))
+
+
+class FeatureExtractor:
+    """Same constructor / call signature as the reference's numpy FeatureExtractor; the
+    arithmetic runs in the HIP log-mel kernel of the model it is attached to."""
+
+    def __init__(self, feature_size=80, sampling_rate=16000, hop_length=160, chunk_length=30, n_fft=400,
+                 backend: Optional[Whisper] = None):
+        if (sampling_rate, hop_length, n_fft) != (16000, 160, 400):
+            raise ValueError("the HIP log-mel kernel is built for sampling_rate=16000, hop_length=160, n_fft=400")
+        self.n_fft, self.hop_length, self.chunk_length = n_fft, hop_length, chunk_length
+        self.n_samples = chunk_length * sampling_rate
+        self.nb_max_frames = self.n_samples // hop_length
+        self.time_per_frame = hop_length / sampling_rate
+        self.sampling_rate = sampling_rate
+        self.feature_size = feature_size
+        self._backend = backend
+
+    def __call__(self, waveform: np.ndarray, padding=160, chunk_length=None) -> np.ndarray:
+        if self._backend is None:
+            raise RuntimeError("FeatureExtractor is not attached to a GPU model (no CPU implementation)")
+        if padding != 160:
+            raise ValueError("only padding=160 (the reference default) is supported")
+        if chunk_length is not None:
+            self.n_samples = chunk_length * self.sampling_rate
+            self.nb_max_frames = self.n_samples // self.hop_length
+        return self._backend.log_mel_full(np.asarray(waveform, dtype=np.float32))
+
+
+class Tokenizer:
+    """Special-token view of the Whisper vocabulary (tokenizer.py:9-112).  Text encode/decode
+    is delegated to a HF `tokenizers.Tokenizer` when a tokenizer.json is available; without
+    one (synthetic weights) ids are rendered as `<id>` so the pipeline still runs end to end."""
+
+    def __init__(self, hf_tokenizer, cfg: WhisperConfig, multilingual: bool, task: Optional[str] = None,
+                 language: Optional[str] = None):
+        self.tokenizer = hf_tokenizer
+        self.cfg = cfg
+        self.sot, self.eot = cfg.sot, cfg.eot
+        self.sot_prev, self.sot_lm = cfg.sot_prev, cfg.sot_lm
+        self.no_speech, self.no_timestamps = cfg.no_speech, cfg.no_timestamps
+        self.transcribe, self.translate = cfg.transcribe, cfg.translate
+        self.timestamp_begin = cfg.timestamp_begin
+        if multilingual:
+            if task not in ("transcribe", "translate"):
+                raise ValueError(f"'{task}' is not a valid task (accepted tasks: transcribe, translate)")
+            names = [s[2:-2] for s in language_token_strings(cfg)]
+            if language not in names:
+                raise ValueError(f"'{language}' is not a valid language code")
+            self.task = cfg.transcribe if task == "transcribe" else cfg.translate
+            self.language = cfg.lang_begin + names.index(language)
+            self.language_code = language
+        else:
+            self.task = None
+            self.language = None
+            self.language_code = "en"
+
+    @property
+    def sot_sequence(self) -> List[int]:
+        seq = [self.sot]
+        if self.language is not None:
+            seq.append(self.language)
+        if self.task is not None:
+            seq.append(self.task)
+        return seq
+
+    @property
+    def non_speech_tokens(self) -> Tuple[int, ...]:
+        # needs the real vocabulary (tokenizer.py:114-148); empty for synthetic models
+        if self.tokenizer is None:
+            return ()
+        symbols = list('"#()*+/:;<=>@[\\]^_`{|}~「」『』') + "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+        miscellaneous = set("♩♪♫♬♭♮♯")
+        result = {self.encode(" -")[0], self.encode(" '")[0]}
+        for symbol in symbols + list(miscellaneous):
+            for tokens in (self.encode(symbol), self.encode(" " + symbol)):
+                if len(tokens) == 1 or symbol in miscellaneous:
+                    result.add(tokens[0])
+        return tuple(sorted(result))
+
+    def encode(self, text: str) -> List[int]:
+        if self.tokenizer is None:
+            raise RuntimeError("text prompts need a tokenizer.json (this model has none)")
+        return self.tokenizer.encode(text, add_special_tokens=False).ids
+
+    def decode(self, tokens: List[int]) -> str:
+        text_tokens = [t for t in tokens if t < self.eot]
+        if self.tokenizer is None:
+            return "".join(f"<{t}>" for t in text_tokens)
+        return self.tokenizer.decode(text_tokens)
+
+
+def get_suppressed_tokens(tokenizer: Tokenizer, suppress_tokens) -> Optional[Tuple[int, ...]]:
+    """suppress set = user ids (-1 expands to the non-speech tokens) + task/sot/no_speech specials,
+    sorted tuple (transcribe.py:1884-1907)"""
+    if -1 in suppress_tokens:
+        suppress_tokens = [t for t in suppress_tokens if t >= 0]
+        suppress_tokens.extend(tokenizer.non_speech_tokens)
+    elif suppress_tokens is None or len(suppress_tokens) == 0:
+        suppress_tokens = []
+    else:
+        assert isinstance(suppress_tokens, list), "suppress_tokens must be a list"
+        suppress_tokens = list(suppress_tokens)
+    suppress_tokens.extend([tokenizer.transcribe, tokenizer.translate, tokenizer.sot, tokenizer.sot_prev,
+                            tokenizer.sot_lm, tokenizer.no_speech])
+    return tuple(sorted(set(suppress_tokens)))
+
+
+class WhisperModel:
+    """Model + the helpers the batched pipeline needs (reference: WhisperModel.__init__ :620-722)."""
+
+    def __init__(self, model_size_or_path: str, device: str = "auto", device_index: Union[int, List[int]] = 0,
+                 compute_type: str = "default", cpu_threads: int = 0, num_workers: int = 1,
+                 download_root: Optional[str] = None, local_files_only: bool = False, files: dict = None,
+                 revision: Optional[str] = None, use_auth_token=None, **model_kwargs):
+        self.logger = _LOG
+        tokenizer_bytes = preprocessor_bytes = None
+        if files:
+            files = dict(files)
+            tokenizer_bytes = files.pop("tokenizer.json", None)
+            preprocessor_bytes = files.pop("preprocessor_config.json", None)
+        model_path = model_size_or_path
+        self.model = Whisper(model_path, device=device, device_index=device_index, compute_type=compute_type,
+                             intra_threads=cpu_threads, inter_threads=num_workers, files=files, **model_kwargs)
+        cfg = self.model.config
+        self.hf_tokenizer = None
+        tok_file = os.path.join(model_path, "tokenizer.json") if isinstance(model_path, str) else ""
+        if tokenizer_bytes or os.path.isfile(tok_file):
+            import tokenizers
+            self.hf_tokenizer = (tokenizers.Tokenizer.from_buffer(tokenizer_bytes) if tokenizer_bytes
+                                 else tokenizers.Tokenizer.from_file(tok_file))
+        self.feat_kwargs = self._get_feature_kwargs(model_path, preprocessor_bytes)
+        self.feat_kwargs.setdefault("feature_size", cfg.n_mels)
+        self.feature_extractor = FeatureExtractor(**self.feat_kwargs, backend=self.model)
+        self.input_stride = 2
+        self.num_samples_per_token = self.feature_extractor.hop_length * self.input_stride
+        self.frames_per_second = self.feature_extractor.sampling_rate // self.feature_extractor.hop_length
+        self.tokens_per_second = self.feature_extractor.sampling_rate // self.num_samples_per_token
+        self.time_precision = 0.02
+        self.max_length = 448
+
+    @property
+    def supported_languages(self) -> List[str]:
+        if not self.model.is_multilingual:
+            return ["en"]
+        return [s[2:-2] for s in language_token_strings(self.model.config)]
+
+    def _get_feature_kwargs(self, model_path, preprocessor_bytes=None) -> dict:
+        config = {}
+        try:
+            path = os.path.join(model_path, "preprocessor_config.json") if isinstance(model_path, str) else ""
+            if preprocessor_bytes:
+                config = json.loads(preprocessor_bytes)
+            elif os.path.isfile(path):
+                with open(path, "r", encoding="utf-8") as f:
+                    config = json.load(f)
+            else:
+                return config
+            valid = ("feature_size", "sampling_rate", "hop_length", "chunk_length", "n_fft")
+            return {k: v for k, v in config.items() if k in valid}
+        except json.JSONDecodeError as e:
+            self.logger.warning("Could not load preprocessor config: %s", e)
+        return config
+
+    def transcribe(self, *args, **kwargs):
+        raise NotImplementedError(
+            "the sequential seek-loop path is outside this tier's hot path (SURVEY.md section 2): use "
+            "BatchedInferencePipeline.transcribe, or run the reference's WhisperModel on faster_whisper_amd.ct2_shim")
+
+    def make_tokenizer(self, task="transcribe", language="en") -> Tokenizer:
+        return Tokenizer(self.hf_tokenizer, self.model.config, self.model.is_multilingual, task=task, language=language)
+
+    # ---- backend wrappers -----------------------------------------------------------------
+    def encode(self, features: np.ndarray) -> StorageView:
+        to_cpu = self.model.device == "cuda" and len(self.model.device_index) > 1
+        if features.ndim == 2:
+            features = np.expand_dims(features, 0)
+        return self.model.encode(StorageView.from_array(np.ascontiguousarray(features)), to_cpu=to_cpu)
+
+    def get_prompt(self, tokenizer: Tokenizer, previous_tokens: List[int], without_timestamps: bool = False,
+                   prefix: Optional[str] = None, hotwords: Optional[str] = None) -> List[int]:
+        prompt = []
+        half = self.max_length // 2
+        if previous_tokens or (hotwords and not prefix):
+            prompt.append(tokenizer.sot_prev)
+            if hotwords and not prefix:
+                hw = tokenizer.encode(" " + hotwords.strip())
+                prompt.extend(hw[:half - 1] if len(hw) >= half else hw)
+            if previous_tokens:
+                prompt.extend(previous_tokens[-(half - 1):])
+        prompt.extend(tokenizer.sot_sequence)
+        if without_timestamps:
+            prompt.append(tokenizer.no_timestamps)
+        if prefix:
+            pt = tokenizer.encode(" " + prefix.strip())
+            if len(pt) >= half:
+                pt = pt[:half - 1]
+            if not without_timestamps:
+                prompt.append(tokenizer.timestamp_begin)
+            prompt.extend(pt)
+        return prompt
+
+    def _split_segments_by_timestamps(self, tokenizer: Tokenizer, tokens: List[int], time_offset: float,
+                                      segment_size: int, segment_duration: float, seek: int):
+        """consecutive-timestamp slicing of one chunk's tokens (transcribe.py:1024-1101)"""
+        tb = tokenizer.timestamp_begin
+        segs = []
+        single_ts_end = len(tokens) >= 2 and tokens[-2] < tb <= tokens[-1]
+        cuts = [i for i in range(1, len(tokens)) if tokens[i] >= tb and tokens[i - 1] >= tb]
+        if cuts:
+            if single_ts_end:
+                cuts.append(len(tokens))
+            last = 0
+            for cur in cuts:
+                piece = tokens[last:cur]
+                segs.append(dict(seek=seek, start=time_offset + (piece[0] - tb) * self.time_precision,
+                                 end=time_offset + (piece[-1] - tb) * self.time_precision, tokens=piece))
+                last = cur
+            if single_ts_end:
+                seek += segment_size
+            else:
+                seek += (tokens[last - 1] - tb) * self.input_stride
+        else:
+            duration = segment_duration
+            stamps = [t for t in tokens if t >= tb]
+            if stamps and stamps[-1] != tb:
+                duration = (stamps[-1] - tb) * self.time_precision
+            segs.append(dict(seek=seek, start=time_offset, end=time_offset + duration, tokens=tokens))
+            seek += segment_size
+        return segs, seek, single_ts_end
+
+    def find_alignment(self, tokenizer: Tokenizer, text_tokens: List[List[int]], encoder_output: StorageView,
+                       num_frames, median_filter_width: int = 7) -> List[dict]:
+        """raw per-token alignment from the backend (transcribe.py:1698-1746): for each chunk the token
+        jump times and token probabilities; the word grouping heuristics stay with the reference host code."""
+        if len(text_tokens) == 0:
+            return []
+        results = self.model.align(encoder_output, tokenizer.sot_sequence, text_tokens, num_frames,
+                                   median_filter_width=median_filter_width)
+        out = []
+        for res in results:
+            if not res.alignments:
+                out.append(dict(jump_times=np.zeros(0), text_token_probs=[]))
+                continue
+            ti = np.array([p[0] for p in res.alignments])
+            fi = np.array([p[1] for p in res.alignments])
+            jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+            out.append(dict(jump_times=fi[jumps] / self.tokens_per_second, text_token_probs=res.text_token_probs))
+        return out
+
+    def detect_language(self, audio: Optional[np.ndarray] = None, features: Optional[np.ndarray] = None,
+                        vad_filter: bool = False, vad_parameters=None, language_detection_segments: int = 1,
+                        language_detection_threshold: float = 0.5):
+        assert audio is not None or features is not None, "Either `audio` or `features` must be provided."
+        if vad_filter:
+            raise NotImplementedError("Silero VAD is a 'next' row of this tier (SURVEY.md section 8f-3)")
+        fe = self.feature_extractor
+        if audio is not None:
+            features = fe(audio[: language_detection_segments * fe.n_samples])
+        features = features[..., : language_detection_segments * fe.nb_max_frames]
+        seen = {}
+        for i in range(0, features.shape[-1], fe.nb_max_frames):
+            enc = self.encode(pad_or_trim(features[..., i:i + fe.nb_max_frames]))
+            results = self.model.detect_language(enc)[0]
+            all_probs = [(tok[2:-2], p) for tok, p in results]
+            language, prob = all_probs[0]
+            if prob > language_detection_threshold:
+                break
+            seen.setdefault(language, []).append(prob)
+        else:
+            language = max(seen, key=lambda k: len(seen[k]))
+            prob = max(seen[language])
+        return language, prob, all_probs
+
+
+class BatchedInferencePipeline:
+    def __init__(self, model: WhisperModel):
+        self.model = model
+        self.last_speech_timestamp = 0.0
+
+    # ---- one batch: encode + generate ---------------------------------------------------
+    def generate_segment_batched(self, features, tokenizer: Tokenizer, options: TranscriptionOptions,
+                                 audio_chunks: Optional[List[np.ndarray]] = None):
+        """features: [B, n_mels, 3000] float32, or None when `audio_chunks` is given (fused resident
+        PCM -> log-mel -> encoder path; the features never leave HBM)."""
+        m = self.model
+        batch_size = len(audio_chunks) if audio_chunks is not None else features.shape[0]
+        prompt = m.get_prompt(tokenizer,
+                              previous_tokens=(tokenizer.encode(options.initial_prompt)
+                                               if isinstance(options.initial_prompt, str)
+                                               else list(options.initial_prompt or [])),
+                              without_timestamps=options.without_timestamps, hotwords=options.hotwords)
+        max_length = len(prompt) + options.max_new_tokens if options.max_new_tokens is not None else m.max_length
+        if max_length > m.max_length:
+            raise ValueError(
+                f"The length of the prompt is {len(prompt)}, and the `max_new_tokens` {max_length - len(prompt)}. "
+                f"Thus, the combined length of the prompt and `max_new_tokens` is: {max_length}. This exceeds the "
+                f"`max_length` of the Whisper model: {m.max_length}. You should either reduce the length of your "
+                f"prompt, or reduce the value of `max_new_tokens`, so that their combined length is less that "
+                f"{m.max_length}.")
+        encoder_output = m.model.encode_pcm(audio_chunks) if audio_chunks is not None else m.encode(features)
+        prompts = [prompt.copy() for _ in range(batch_size)]
+        if options.multilingual:
+            names = language_token_strings(m.model.config)
+            lang_tokens = [m.model.config.lang_begin + names.index(r[0][0]) for r in
+                           m.model.detect_language(encoder_output)]
+            idx = prompt.index(tokenizer.language)
+            for i, t in enumerate(lang_tokens):
+                prompts[i][idx] = t
+        results = m.model.generate(
+            encoder_output, prompts, beam_size=options.beam_size, patience=options.patience,
+            length_penalty=options.length_penalty, max_length=max_length, suppress_blank=options.suppress_blank,
+            suppress_tokens=options.suppress_tokens, return_scores=True, return_no_speech_prob=True,
+            sampling_temperature=options.temperatures[0], repetition_penalty=options.repetition_penalty,
+            no_repeat_ngram_size=options.no_repeat_ngram_size)
+        output = []
+        for r in results:
+            n = len(r.sequences_ids[0])
+            cum = r.scores[0] * (n ** options.length_penalty)
+            output.append(dict(avg_logprob=cum / (n + 1), no_speech_prob=r.no_speech_prob, tokens=r.sequences_ids[0]))
+        return encoder_output, output
+
+    def forward(self, features, tokenizer, chunks_metadata, options, audio_chunks=None):
+        encoder_output, outputs = self.generate_segment_batched(features, tokenizer, options, audio_chunks)
+        return self._segment_outputs(outputs, tokenizer, chunks_metadata, options, encoder_output)
+
+    def _segment_outputs(self, outputs, tokenizer, chunks_metadata, options, encoder_output=None):
+        m = self.model
+        segmented, sizes = [], []
+        for meta, out in zip(chunks_metadata, outputs):
+            duration = meta["duration"]
+            size = int(ceil(duration) * m.frames_per_second)
+            sizes.append(size)
+            subs, _, _ = m._split_segments_by_timestamps(tokenizer=tokenizer, tokens=out["tokens"],
+                                                         time_offset=meta["offset"], segment_size=size,
+                                                         segment_duration=duration, seek=0)
+            segmented.append([
+                dict(text=tokenizer.decode(s["tokens"]), avg_logprob=out["avg_logprob"],
+                     no_speech_prob=out["no_speech_prob"], tokens=s["tokens"], start=s["start"], end=s["end"],
+                     compression_ratio=get_compression_ratio(tokenizer.decode(s["tokens"]) or " "),
+                     seek=int(meta["offset"] * m.frames_per_second))
+                for s in subs])
+        if options.word_timestamps:
+            raise NotImplementedError(
+                "word_timestamps needs the reference's add_word_timestamps heuristics (out of scope for this tier); "
+                "WhisperModel.find_alignment exposes the backend alignment")
+        return segmented
+
+    # ---- the public entry point ---------------------------------------------------------
+    def transcribe(self, audio: Union[str, np.ndarray], language: Optional[str] = None, task: str = "transcribe",
+                   log_progress: bool = False, beam_size: int = 5, best_of: int = 5, patience: float = 1,
+                   length_penalty: float = 1, repetition_penalty: float = 1, no_repeat_ngram_size: int = 0,
+                   temperature=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), compression_ratio_threshold: Optional[float] = 2.4,
+                   log_prob_threshold: Optional[float] = -1.0, no_speech_threshold: Optional[float] = 0.6,
+                   condition_on_previous_text: bool = True, prompt_reset_on_temperature: float = 0.5,
+                   initial_prompt=None, prefix: Optional[str] = None, suppress_blank: bool = True,
+                   suppress_tokens: Optional[List[int]] = [-1], without_timestamps: bool = True,
+                   max_initial_timestamp: float = 1.0, word_timestamps: bool = False,
+                   prepend_punctuations: str = "\"'“¿([{-", append_punctuations: str = "\"'.。,，!！?？:：”)]}、",
+                   multilingual: bool = False, vad_filter: bool = True, vad_parameters=None,
+                   max_new_tokens: Optional[int] = None, chunk_length: Optional[int] = None,
+                   clip_timestamps: Optional[List[dict]] = None, hallucination_silence_threshold=None,
+                   batch_size: int = 8, hotwords: Optional[str] = None,
+                   language_detection_threshold: Optional[float] = 0.5, language_detection_segments: int = 1,
+                   shard: bool = False, fused_features: bool = True):
+        """Same contract as the reference (transcribe.py:254-578): returns (segment generator, info).
+        shard=True: inside a torch.distributed job every rank calls this with the same arguments; the
+        chunk list is block-partitioned over the ranks and rank 0's generator yields ALL segments in
+        order (other ranks yield nothing).  fused_features=False reproduces the reference data flow
+        (features materialised on the host, then encode())."""
+        m = self.model
+        sr = m.feature_extractor.sampling_rate
+        if multilingual and not m.model.is_multilingual:
+            m.logger.warning("The current model is English-only but the multilingual parameter is set to"
+                             "True; setting to False instead.")
+            multilingual = False
+        if not isinstance(audio, np.ndarray):
+            raise NotImplementedError("audio decoding (PyAV) is outside this tier: pass a 16 kHz float32 ndarray")
+        audio = np.asarray(audio, dtype=np.float32)
+        duration = audio.shape[0] / sr
+        chunk_length = chunk_length or m.feature_extractor.chunk_length
+        if not clip_timestamps:
+            if duration < chunk_length:
+                clip_timestamps = [{"start": 0.0, "end": duration}]
+            elif vad_filter:
+                raise NotImplementedError(
+                    "Silero VAD chunking is a 'next' row of this tier (SURVEY.md section 8f-3): provide "
+                    "clip_timestamps=[{'start': s, 'end': e}, ...] (seconds)")
+            else:
+                raise RuntimeError("No clip timestamps found. Set 'vad_filter' to True or provide 'clip_timestamps'.")
+        clips = [{k: int(v * sr) for k, v in seg.items()} for seg in clip_timestamps]
+        audio_chunks, chunks_metadata = [], []
+        for i, clip in enumerate(clips):
+            audio_chunks.append(audio[clip["start"]:clip["end"]])
+            d = (clip["end"] - clip["start"]) / sr
+            if d > 30:
+                m.logger.warning("Segment %d is longer than 30 seconds, only the first 30 seconds will be "
+                                 "transcribed", i)
+            chunks_metadata.append({"offset": clip["start"] / sr, "duration": d, "segments": [clip]})
+        duration_after_vad = sum(c["end"] - c["start"] for c in clips) / sr
+
+        all_language_probs = None
+        if language is None:
+            if not m.model.is_multilingual:
+                language, language_probability = "en", 1
+            else:
+                feats = np.concatenate([m.model.log_mel(audio_chunks[:1])[0]]
+                                       + [np.full((m.model.n_mels, 1), -1.5, dtype="float32")], axis=1)
+                language, language_probability, all_language_probs = m.detect_language(
+                    features=feats, language_detection_segments=language_detection_segments,
+                    language_detection_threshold=language_detection_threshold)
+        else:
+            if not m.model.is_multilingual and language != "en":
+                m.logger.warning("The current model is English-only but the language parameter is set to '%s'; "
+                                 "using 'en' instead." % language)
+                language = "en"
+            language_probability = 1
+        tokenizer = m.make_tokenizer(task=task, language=language)
+        options = TranscriptionOptions(
+            beam_size=beam_size, best_of=best_of, patience=patience, length_penalty=length_penalty,
+            repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
+            log_prob_threshold=log_prob_threshold, no_speech_threshold=no_speech_threshold,
+            compression_ratio_threshold=compression_ratio_threshold,
+            temperatures=(list(temperature[:1]) if isinstance(temperature, (list, tuple)) else [temperature]),
+            initial_prompt=initial_prompt, prefix=prefix, suppress_blank=suppress_blank,
+            suppress_tokens=(get_suppressed_tokens(tokenizer, list(suppress_tokens)) if suppress_tokens
+                             else suppress_tokens),
+            prepend_punctuations=prepend_punctuations, append_punctuations=append_punctuations,
+            max_new_tokens=max_new_tokens, hotwords=hotwords, word_timestamps=word_timestamps,
+            hallucination_silence_threshold=None, condition_on_previous_text=False,
+            clip_timestamps=clip_timestamps, prompt_reset_on_temperature=0.5, multilingual=multilingual,
+            without_timestamps=without_timestamps, max_initial_timestamp=0.0)
+        info = TranscriptionInfo(language=language, language_probability=language_probability, duration=duration,
+                                 duration_after_vad=duration_after_vad, transcription_options=options,
+                                 vad_options=vad_parameters, all_language_probs=all_language_probs)
+        gen = self._batched_segments_generator(audio_chunks, tokenizer, chunks_metadata, batch_size, options,
+                                               log_progress, shard, fused_features)
+        return gen, info
+
+    def _batched_segments_generator(self, audio_chunks, tokenizer, chunks_metadata, batch_size, options,
+                                    log_progress, shard=False, fused_features=True):
+        from .sharding import gather_results, partition
+        m = self.model
+        rank, world, local_rank = 0, 1, 0
+        if shard:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        n = len(audio_chunks)
+        bounds = partition(n, world)
+        lo, hi = bounds[rank]
+        max_len = m.max_length
+        seg_idx = 0
+        # every rank walks the same number of batch rounds so the per-round gather lines up
+        rounds = max((b[1] - b[0] + batch_size - 1) // batch_size for b in bounds) if n else 0
+        per_rank_outputs = [[] for _ in range(world)]
+        for rnd in range(rounds):
+            i0 = lo + rnd * batch_size
+            i1 = min(hi, i0 + batch_size)
+            outs = []
+            if i0 < i1:
+                chunks = audio_chunks[i0:i1]
+                if fused_features:
+                    _, outs = self.generate_segment_batched(None, tokenizer, options, audio_chunks=chunks)
+                else:
+                    feats = m.model.log_mel(chunks)
+                    _, outs = self.generate_segment_batched(feats, tokenizer, options)
+            if world == 1:
+                per_rank_outputs[0].extend(outs)
+            else:
+                counts = [max(0, min(b[1], b[0] + (rnd + 1) * batch_size) - (b[0] + rnd * batch_size)) for b in bounds]
+                recs = _OutRec.wrap(outs)
+                got = gather_results(recs, max_len, rank, world, local_rank, counts=counts)
+                if rank == 0:
+                    pos = 0
+                    for r in range(world):
+                        for (ids, avg_lp, nsp) in got[pos:pos + counts[r]]:
+                            per_rank_outputs[r].append(dict(tokens=ids, avg_logprob=avg_lp, no_speech_prob=nsp))
+                        pos += counts[r]
+        if rank != 0:
+            return
+        ordered = [o for r in range(world) for o in per_rank_outputs[r]]
+        results = self._segment_outputs(ordered, tokenizer, chunks_metadata, options)
+        for result in results:
+            for seg in result:
+                seg_idx += 1
+                yield Segment(seek=seg["seek"], id=seg_idx, text=seg["text"], start=round(seg["start"], 3),
+                              end=round(seg["end"], 3), words=None, tokens=seg["tokens"],
+                              avg_logprob=seg["avg_logprob"], no_speech_prob=seg["no_speech_prob"],
+                              compression_ratio=seg["compression_ratio"], temperature=options.temperatures[0])
+        self.last_speech_timestamp = 0.0
+
+
+class _OutRec:
+    """adapts the pipeline's per-chunk dicts to the record layout of sharding.gather_results
+    (ids, one float score slot = avg_logprob, no_speech_prob)"""
+
+    def __init__(self, d):
+        self.sequences_ids = [d["tokens"]]
+        self.scores = [d["avg_logprob"]]
+        self.no_speech_prob = d["no_speech_prob"]
+
+    @staticmethod
+    def wrap(outs):
+        return [_OutRec(o) for o in outs]

@@ -140,6 +140,11 @@ int32_t fw_model_create(const fw_config* cfg, const fw_weight* weights, int32_t 
 void fw_model_free(fw_model* m);
 int32_t fw_model_info(const fw_model* m, fw_config* cfg_out, int32_t* compute_type,
                       int32_t* device_index, int32_t* max_batch, int32_t* max_beam);
+/* Device address / size of a model's weight blob: lets N worker replicas on one GPU share one copy
+ * of the weights (CTranslate2's inter_threads / faster-whisper's num_workers, transcribe.py:654-657):
+ * create the extra replicas with fw_model_create_from_blob_dev on this pointer. The owning model
+ * must outlive them. */
+int32_t fw_model_blob(const fw_model* m, void** blob_dev, int64_t* blob_bytes);
 /* Same model from a weight blob that is ALREADY in HBM on `device_index`
  * (the RCCL-broadcast path: rank 0 packs, ranks receive into device memory).
  * blob layout: faster_whisper_amd/weights.py::pack_blob. */

@@ -1,0 +1,111 @@
+"""Host-side integer logic of the batched path (no GPU): prompt construction, suppress set,
+timestamp splitting, pad_or_trim, chunk partitioning, result records.  Expected values are
+worked out by hand from the reference's rules (transcribe.py:1024-1101, :1532-1565, :1884-1907)."""
+import numpy as np
+import pytest
+
+from faster_whisper_amd import get_config
+from faster_whisper_amd.sharding import decode_records, encode_records, partition
+from faster_whisper_amd.transcribe import (Tokenizer, WhisperModel, get_compression_ratio, get_suppressed_tokens,
+                                           pad_or_trim)
+
+
+def _bare_model(cfg):
+    m = WhisperModel.__new__(WhisperModel)
+    m.max_length = 448
+    m.time_precision = 0.02
+    m.input_stride = 2
+    m.frames_per_second = 100
+    m.tokens_per_second = 50
+    return m
+
+
+def test_tokenizer_special_ids_and_sot_sequence():
+    v3 = get_config("large-v3")
+    tok = Tokenizer(None, v3, True, task="transcribe", language="fr")
+    assert tok.sot_sequence == [50258, 50259 + 6, 50360]   # fr is the 7th language of the vocabulary
+    assert tok.timestamp_begin == 50365 and tok.no_timestamps == 50364
+    en = get_config("tiny.en")
+    tok_en = Tokenizer(None, en, False)
+    assert tok_en.sot_sequence == [50257]
+    with pytest.raises(ValueError):
+        Tokenizer(None, v3, True, task="nope", language="en")
+    with pytest.raises(ValueError):
+        Tokenizer(None, v3, True, task="transcribe", language="xx")
+
+
+def test_get_prompt():
+    cfg = get_config("large-v3")
+    m = _bare_model(cfg)
+    tok = Tokenizer(None, cfg, True, task="transcribe", language="en")
+    assert m.get_prompt(tok, [], without_timestamps=True) == [50258, 50259, 50360, 50364]
+    assert m.get_prompt(tok, [], without_timestamps=False) == [50258, 50259, 50360]
+    prev = list(range(1000, 1300))
+    p = m.get_prompt(tok, prev, without_timestamps=True)
+    assert p[0] == cfg.sot_prev and p[1:224] == prev[-223:] and p[224:] == [50258, 50259, 50360, 50364]
+
+
+def test_suppressed_tokens_matches_reference_rule():
+    en = get_config("tiny.en")
+    tok = Tokenizer(None, en, False)
+    got = get_suppressed_tokens(tok, [-1])
+    # without a vocabulary the non-speech set is empty; the six specials are pinned by the
+    # reference's tests/test_tokenizer.py:110
+    assert got == (50257, 50357, 50358, 50359, 50360, 50361)
+    assert get_suppressed_tokens(tok, [5, 3]) == (3, 5, 50257, 50357, 50358, 50359, 50360, 50361)
+
+
+def test_split_segments_by_timestamps():
+    cfg = get_config("large-v3")
+    m = _bare_model(cfg)
+    tok = Tokenizer(None, cfg, True, task="transcribe", language="en")
+    tb = cfg.timestamp_begin
+    # <0.00> a b <2.00><2.00> c <4.50>   -> two segments, single timestamp ending
+    tokens = [tb, 11, 12, tb + 100, tb + 100, 13, tb + 225]
+    segs, seek, single = m._split_segments_by_timestamps(tok, tokens, time_offset=30.0, segment_size=3000,
+                                                         segment_duration=30.0, seek=0)
+    assert single is True and seek == 3000
+    assert [s["tokens"] for s in segs] == [[tb, 11, 12, tb + 100], [tb + 100, 13, tb + 225]]
+    assert segs[0]["start"] == pytest.approx(30.0) and segs[0]["end"] == pytest.approx(32.0)
+    assert segs[1]["start"] == pytest.approx(32.0) and segs[1]["end"] == pytest.approx(34.5)
+    # consecutive timestamps but no single-timestamp ending: seek advances to the last pair
+    tokens = [tb, 11, tb + 50, tb + 50, 12, 13]
+    segs, seek, single = m._split_segments_by_timestamps(tok, tokens, 0.0, 3000, 30.0, 0)
+    assert single is False and len(segs) == 1 and seek == 50 * 2
+    # no consecutive timestamps: one segment, duration from the last timestamp
+    tokens = [11, 12, tb + 200]
+    segs, seek, _ = m._split_segments_by_timestamps(tok, tokens, 60.0, 3000, 30.0, 0)
+    assert len(segs) == 1 and segs[0]["end"] == pytest.approx(64.0) and seek == 3000
+    # text only: whole chunk
+    segs, seek, _ = m._split_segments_by_timestamps(tok, [11, 12], 0.0, 2500, 25.0, 0)
+    assert segs[0]["start"] == 0.0 and segs[0]["end"] == 25.0 and seek == 2500
+
+
+def test_pad_or_trim_and_compression_ratio():
+    a = np.arange(12, dtype=np.float32).reshape(2, 6)
+    assert pad_or_trim(a, 4).shape == (2, 4) and np.array_equal(pad_or_trim(a, 4), a[:, :4])
+    p = pad_or_trim(a, 9)
+    assert p.shape == (2, 9) and np.array_equal(p[:, :6], a) and float(np.abs(p[:, 6:]).max()) == 0.0
+    assert get_compression_ratio("a" * 100) > 5
+
+
+def test_partition_is_contiguous_and_balanced():
+    for n, w in [(120, 8), (10, 4), (3, 8), (0, 2), (17, 1)]:
+        parts = partition(n, w)
+        assert len(parts) == w and parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in parts]
+        assert max(sizes) - min(sizes) <= 1
+    assert partition(120, 8)[3] == (45, 60)
+
+
+def test_result_records_roundtrip():
+    class R:
+        def __init__(self, ids, s, n):
+            self.sequences_ids, self.scores, self.no_speech_prob = [ids], [s], n
+    rs = [R([1, 2, 3], -0.25, 0.5), R([], -1.5, 0.0), R(list(range(40)), 0.0, 1.0)]
+    rec = encode_records(rs, 32)
+    assert rec.shape == (3, 35) and rec.dtype == np.int32
+    back = decode_records(rec, 32)
+    assert back[0] == ([1, 2, 3], -0.25, 0.5) and back[1] == ([], -1.5, 0.0)
+    assert back[2][0] == list(range(32))   # truncated to max_len

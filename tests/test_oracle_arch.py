@@ -1,0 +1,95 @@
+"""Architecture cross-check of the CPU oracle against an independent implementation of the
+same network: the installed `transformers` WhisperForConditionalGeneration loaded with the
+SAME synthetic weights (the only executable second opinion in this
+environment).  Confirms layer order, pre-norm placement, exact-erf GELU, bias-free key
+projection, [sin|cos] encoder positions, learned decoder positions, tied output embedding."""
+import numpy as np
+import pytest
+import torch
+
+from faster_whisper_amd import get_config, synthetic_weights
+from oracle.whisper import OracleWhisper
+
+transformers = pytest.importorskip("transformers")
+
+
+def _load_into_hf(cfg, w):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    hc = WhisperConfig(vocab_size=cfg.n_vocab, num_mel_bins=cfg.n_mels, encoder_layers=cfg.n_enc_layers,
+                       encoder_attention_heads=cfg.n_heads, decoder_layers=cfg.n_dec_layers,
+                       decoder_attention_heads=cfg.n_heads, decoder_ffn_dim=4 * cfg.d_model,
+                       encoder_ffn_dim=4 * cfg.d_model, d_model=cfg.d_model, max_source_positions=cfg.n_audio_ctx,
+                       max_target_positions=cfg.n_text_ctx, pad_token_id=cfg.eot, bos_token_id=cfg.eot,
+                       eos_token_id=cfg.eot, decoder_start_token_id=cfg.sot, activation_function="gelu",
+                       dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    model = WhisperForConditionalGeneration(hc).eval()
+    sd = {}
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    d = cfg.d_model
+
+    def attn(prefix, qkv_w, qkv_b, out_w, out_b):
+        sd[prefix + "q_proj.weight"], sd[prefix + "k_proj.weight"], sd[prefix + "v_proj.weight"] = t(qkv_w).split(d)
+        qb, _, vb = t(qkv_b).split(d)
+        sd[prefix + "q_proj.bias"], sd[prefix + "v_proj.bias"] = qb, vb
+        sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"] = t(out_w), t(out_b)
+
+    sd["model.encoder.conv1.weight"], sd["model.encoder.conv1.bias"] = t(w["enc.conv1.w"]), t(w["enc.conv1.b"])
+    sd["model.encoder.conv2.weight"], sd["model.encoder.conv2.bias"] = t(w["enc.conv2.w"]), t(w["enc.conv2.b"])
+    sd["model.encoder.embed_positions.weight"] = t(w["enc.pos"])
+    for i in range(cfg.n_enc_layers):
+        p, q = f"model.encoder.layers.{i}.", f"enc.{i}."
+        attn(p + "self_attn.", w[q + "attn.qkv.w"], w[q + "attn.qkv.b"], w[q + "attn.out.w"], w[q + "attn.out.b"])
+        sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"] = t(w[q + "ln1.g"]), t(w[q + "ln1.b"])
+        sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = t(w[q + "ln2.g"]), t(w[q + "ln2.b"])
+        sd[p + "fc1.weight"], sd[p + "fc1.bias"] = t(w[q + "ffn1.w"]), t(w[q + "ffn1.b"])
+        sd[p + "fc2.weight"], sd[p + "fc2.bias"] = t(w[q + "ffn2.w"]), t(w[q + "ffn2.b"])
+    sd["model.encoder.layer_norm.weight"], sd["model.encoder.layer_norm.bias"] = t(w["enc.ln_post.g"]), t(w["enc.ln_post.b"])
+    sd["model.decoder.embed_tokens.weight"] = t(w["dec.tok_emb"])
+    sd["model.decoder.embed_positions.weight"] = t(w["dec.pos"])
+    for i in range(cfg.n_dec_layers):
+        p, q = f"model.decoder.layers.{i}.", f"dec.{i}."
+        attn(p + "self_attn.", w[q + "self.qkv.w"], w[q + "self.qkv.b"], w[q + "self.out.w"], w[q + "self.out.b"])
+        sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"] = t(w[q + "ln1.g"]), t(w[q + "ln1.b"])
+        kvw, kvb = t(w[q + "cross.kv.w"]), t(w[q + "cross.kv.b"])
+        sd[p + "encoder_attn.q_proj.weight"], sd[p + "encoder_attn.q_proj.bias"] = t(w[q + "cross.q.w"]), t(w[q + "cross.q.b"])
+        sd[p + "encoder_attn.k_proj.weight"], sd[p + "encoder_attn.v_proj.weight"] = kvw.split(d)
+        sd[p + "encoder_attn.v_proj.bias"] = kvb.split(d)[1]
+        sd[p + "encoder_attn.out_proj.weight"], sd[p + "encoder_attn.out_proj.bias"] = t(w[q + "cross.out.w"]), t(w[q + "cross.out.b"])
+        sd[p + "encoder_attn_layer_norm.weight"], sd[p + "encoder_attn_layer_norm.bias"] = t(w[q + "ln2.g"]), t(w[q + "ln2.b"])
+        sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = t(w[q + "ln3.g"]), t(w[q + "ln3.b"])
+        sd[p + "fc1.weight"], sd[p + "fc1.bias"] = t(w[q + "ffn1.w"]), t(w[q + "ffn1.b"])
+        sd[p + "fc2.weight"], sd[p + "fc2.bias"] = t(w[q + "ffn2.w"]), t(w[q + "ffn2.b"])
+    sd["model.decoder.layer_norm.weight"], sd["model.decoder.layer_norm.bias"] = t(w["dec.ln.g"]), t(w["dec.ln.b"])
+    sd["proj_out.weight"] = t(w["dec.tok_emb"])
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.endswith("k_proj.bias") for m in missing), missing   # Whisper has no key bias
+    return model
+
+
+def test_oracle_matches_transformers_whisper():
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=3, dtype=np.float32)
+    hf = _load_into_hf(cfg, w)
+    oracle = OracleWhisper(cfg, w, emulate_fp16=False)
+    rng = np.random.default_rng(0)
+    feats = rng.standard_normal((2, cfg.n_mels, 3000)).astype(np.float32) * 0.5
+    tokens = torch.tensor([[cfg.sot, cfg.lang_begin, cfg.transcribe, 11, 12, 13], [cfg.sot, cfg.lang_begin + 1,
+                                                                                  cfg.transcribe, 50, 60, 70]])
+    with torch.no_grad():
+        enc_hf = hf.model.encoder(torch.from_numpy(feats)).last_hidden_state.numpy()
+        logits_hf = hf(input_features=torch.from_numpy(feats), decoder_input_ids=tokens).logits.numpy()
+    enc = oracle.encode(feats)
+    assert np.abs(enc - enc_hf).max() < 2e-4 * max(1.0, np.abs(enc_hf).max())
+    with torch.no_grad():
+        ckv = oracle.cross_kv(torch.from_numpy(enc))
+        hidden = oracle.decoder_full(tokens, ckv)
+        logits = oracle.logits(hidden).numpy()
+    assert np.abs(logits - logits_hf).max() < 5e-4 * max(1.0, np.abs(logits_hf).max())
+    # the KV-cached step path of the oracle equals its own teacher-forced pass
+    with torch.no_grad():
+        cache = oracle._Cache(cfg.n_dec_layers)
+        for pos in range(tokens.shape[1]):
+            h = oracle.decoder_step(tokens[:, pos], pos, cache, ckv)
+        step_logits = oracle.logits(h).numpy()
+    assert np.abs(step_logits - logits[:, -1]).max() < 1e-4
