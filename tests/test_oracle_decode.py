@@ -140,4 +140,5 @@ def test_topk_median_dtw_helpers():
     assert ti.tolist() == [0, 1, 2] and fi.tolist() == [0, 1, 2]
     # more frames than tokens: every token row is visited, the path is monotone and ends in the corner
     ti, fi = _dtw(np.array([[-1.0, -1.0, 0.0, 0.0], [0.0, 0.0, -1.0, -1.0]]))
-    assert ti.tolist() == [0, 0, 1, 1] and fi.tolist() == [0, 1, 2, 3]
+    # (ties in the recurrence fall through to the "left" move, exactly like openai's dtw_cpu)
+    assert ti.tolist() == [0, 0, 1, 1, 1] and fi.tolist() == [0, 1, 1, 2, 3]
