@@ -30,6 +30,28 @@ def test_oracle_matches_reference_golden(golden_dir, n_mels):
         assert float(np.abs(full[..., g["full_idx"]] - g["full_last"]).max()) <= 1e-6, name
 
 
+def test_c_restatement_matches_reference_golden(golden_dir):
+    """oracle/logmel_ref.c (DFT by definition, double precision) vs the reference's float32 FFT:
+    the difference is float32 round-off of the power spectrum only."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(__file__), "..", "oracle")
+    subprocess.run(["make", "-C", here, "-s"], check=True)
+    lib = C.CDLL(os.path.join(here, "_build", "liblogmel_ref.so"))
+    lib.fw_oracle_logmel_full.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long]
+    pcm = np.ascontiguousarray(np.load(f"{golden_dir}/speech_pcm.npz")["pcm"][:32000])
+    for n_mels in (80, 128):
+        nf = pcm.shape[0] // 160 + 1
+        out = np.empty((n_mels, nf), np.float32)
+        assert lib.fw_oracle_logmel_full(pcm.ctypes.data, pcm.shape[0], n_mels, out.ctypes.data, nf) == 0
+        ref = olm.log_mel_full(pcm, n_mels)
+        assert float(np.abs(out - ref).max()) < 1e-4
+    empty = np.empty((80, 1), np.float32)
+    assert lib.fw_oracle_logmel_full(None, 0, 80, empty.ctypes.data, 1) == 0
+    assert abs(float(empty[0, 0]) + 1.5) < 1e-6
+
+
 def test_edge_cases():
     # empty chunk: one frame of the floor value, then dropped -> all zeros after pad_or_trim
     out = olm.log_mel_chunks([np.zeros(0, np.float32)], 80)
