@@ -14,8 +14,12 @@
  *   int fw_oracle_logmel_full(const float* pcm, long n, int n_mels, float* out, long out_frames)
  *        out: [n_mels][n/160 + 1]  == FeatureExtractor.__call__(pcm)
  */
+#define _USE_MATH_DEFINES
 #include <math.h>
 #include <stdlib.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #include <string.h>
 
 #define N_FFT 400
