@@ -56,20 +56,20 @@ struct DgFrag {
   half8_t x[CH][MT];
 };
 
-template <int MT, int NTW, int CH, bool LNF, bool OUT_F32>
-__global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict__ x, int ldx,
+template <int MT, int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool OUT_F32>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(const half_t* __restrict__ x, int ldx,
                                                        const half_t* __restrict__ W,
                                                        const half_t* __restrict__ bias,
                                                        const float* __restrict__ s1, const float* __restrict__ cf,
                                                        const half_t* __restrict__ res, int ldr, void* __restrict__ outv,
                                                        int ldo, int R, int N, int K, int act) {
   extern __shared__ __attribute__((aligned(16))) float dg_smem[];
-  float* red = dg_smem;                                  // [4][MT*NTW][64][4]
-  float* stat = dg_smem + 4 * MT * NTW * 256;            // [4][MT][16][2]
+  float* red = dg_smem;                                  // [WAVES][MT*NTW][64][4]
+  float* stat = dg_smem + WAVES * MT * NTW * 256;        // [WAVES][MT][16][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (16 * NTW);
-  const int kq = K >> 2;  // per-wave K range
+  const int kq = K / WAVES;  // per-wave K range
   const int kbase = wave * kq + g * 8;
   const int steps = kq >> 5;
   const half_t* wp[NTW];
@@ -129,13 +129,20 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict_
         }
       }
   };
-  DgFrag<MT, NTW, CH> fa, fb;
-  load(fa, 0);
-  for (int ks0 = 0; ks0 < steps; ks0 += 2 * CH) {
-    load(fb, ks0 + CH);
+  if (ONESHOT) {
+    // the wave's whole K range fits one register set: every load of the launch is in flight at once
+    DgFrag<MT, NTW, CH> fa;
+    load(fa, 0);
     compute(fa);
-    load(fa, ks0 + 2 * CH);
-    compute(fb);
+  } else {
+    DgFrag<MT, NTW, CH> fa, fb;
+    load(fa, 0);
+    for (int ks0 = 0; ks0 < steps; ks0 += 2 * CH) {
+      load(fb, ks0 + CH);
+      compute(fa);
+      load(fa, ks0 + 2 * CH);
+      compute(fb);
+    }
   }
   // ---- cross-wave reduction (fixed order) ----
 #pragma unroll
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict_
     }
   }
   __syncthreads();
-  for (int idx = wave; idx < MT * NTW; idx += 4) {
+  for (int idx = wave; idx < MT * NTW; idx += WAVES) {
     const int mt = idx / NTW, t = idx - mt * NTW;
     const int row = mt * 16 + i;
     if (row >= R) continue;
@@ -167,13 +174,16 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(const half_t* __restrict_
     for (int e = 0; e < 4; ++e) {
       const int o = (idx * 64 + lane) * 4 + e;
       const int ws = MT * NTW * 256;
-      v[e] = ((red[o] + red[ws + o]) + red[2 * ws + o]) + red[3 * ws + o];
+      float a = red[o];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) a += red[w * ws + o];   // fixed order: deterministic
+      v[e] = a;
     }
     float mu = 0.f, rstd = 1.f;
     if (LNF) {
       float sa = 0.f, sb = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < WAVES; ++w) {
         sa += stat[((w * MT + mt) * 16 + i) * 2];
         sb += stat[((w * MT + mt) * 16 + i) * 2 + 1];
       }
@@ -812,26 +822,27 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
   dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, d, d_step, pos_fixed, P);
 }
 
-template <int MT, int NTW, int CH, bool LNF, bool F32>
+template <int MT, int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool F32>
 static void gemm_go(hipStream_t st, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
                     const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
                     int K, int act) {
-  const size_t lds = (size_t)(4 * MT * NTW * 256 + 4 * MT * 16 * 2) * sizeof(float);
+  const size_t lds = (size_t)(WAVES * MT * NTW * 256 + WAVES * MT * 16 * 2) * sizeof(float);
   static bool attr_set = false;  // one flag per instantiation
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MT, NTW, CH, LNF, F32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(dec_gemm_kernel<MT, NTW, CH, WAVES, ONESHOT, LNF, F32>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dec_gemm_kernel<MT, NTW, CH, LNF, F32><<<grid, 256, lds, st>>>(x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K,
-                                                              act);
+  dec_gemm_kernel<MT, NTW, CH, WAVES, ONESHOT, LNF, F32><<<grid, WAVES * 64, lds, st>>>(x, ldx, W, bias, s1, cf, res, ldr,
+                                                                                   out, ldo, R, N, K, act);
 }
 
-template <int NTW, int CH, bool LNF, bool F32>
+template <int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool F32>
 static int gemm_mt(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
                    const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
                    int K, int act) {
-#define GO(MT) gemm_go<MT, NTW, CH, LNF, F32>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act)
+#define GO(MT) gemm_go<MT, NTW, CH, WAVES, ONESHOT, LNF, F32>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act)
   switch (mt) {
     case 1: GO(1); break;
     case 2: GO(2); break;
@@ -844,6 +855,20 @@ static int gemm_mt(hipStream_t st, int mt, int grid, const half_t* x, int ldx, c
   return 0;
 }
 
+template <int NTW, bool LNF, bool F32>
+static int gemm_k(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+                  const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K,
+                  int act) {
+#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act
+  // K split over the waves of a workgroup so that a wave's share is <= 5 MFMA k-steps whenever
+  // possible: then ALL loads of the launch are issued at once (one memory latency per GEMM).
+  if (K % 256 == 0 && K / 256 <= 5) return gemm_mt<NTW, 5, 8, true, LNF, F32>(ARGS);    // K <= 1280: 8 waves, one shot
+  if (K % 256 == 0) return gemm_mt<NTW, 4, 8, false, LNF, F32>(ARGS);                   // long K: 8 waves, pipelined
+  if (K / 128 <= 5) return gemm_mt<NTW, 5, 4, true, LNF, F32>(ARGS);                    // small K: 4 waves, one shot
+  return gemm_mt<NTW, 3, 4, false, LNF, F32>(ARGS);
+#undef ARGS
+}
+
 // x [R][ldx] fp16 (raw residual stream when s1/cf are given = LayerNorm folded), W [N][K] fp16.
 int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
@@ -851,21 +876,17 @@ int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, c
   if (K % 128 != 0 || R < 1 || R > 80) return -1;
   const int mt = (R + 15) / 16;
   const bool lnf = s1 != nullptr;
-  // columns per workgroup: keep the grid near one wave of workgroups over the 256 CUs
-  const int ntw = (N <= 4096) ? 1 : (N <= 8192 ? 2 : 4);
+  // columns per workgroup: 16 keeps more workgroups in flight, 32 halves the L2->L1 re-read of x
+  const int ntw = (N <= 4096) ? 1 : 2;
   const int grid = (N + 16 * ntw - 1) / (16 * ntw);
+#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act
   if (out_f32) {
     if (!lnf) return -1;
-    if (ntw == 4) return gemm_mt<4, 2, true, true>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
-    if (ntw == 2) return gemm_mt<2, 3, true, true>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
-    return gemm_mt<1, 3, true, true>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+    return ntw == 2 ? gemm_k<2, true, true>(ARGS) : gemm_k<1, true, true>(ARGS);
   }
-  if (lnf) {
-    if (ntw >= 2) return gemm_mt<2, 3, true, false>(st, mt, (N + 31) / 32, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
-    return gemm_mt<1, 3, true, false>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
-  }
-  if (ntw >= 2) return gemm_mt<2, 3, false, false>(st, mt, (N + 31) / 32, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
-  return gemm_mt<1, 3, false, false>(st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act);
+  if (lnf) return ntw == 2 ? gemm_k<2, true, false>(ARGS) : gemm_k<1, true, false>(ARGS);
+  return ntw == 2 ? gemm_k<2, false, false>(ARGS) : gemm_k<1, false, false>(ARGS);
+#undef ARGS
 }
 
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,

@@ -171,6 +171,10 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     ProfScope ps(m, PF_DEC_MISC, 0, 0);
     fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, rows, d, g->d_step, s.pos_fixed, s.P);
   }
+  // one decoder linear: x[rows][K] -> out[rows][N]; LayerNorm-folded when L.s1 is set; in-place residual
+  auto lin = [&](const half_t* xin, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
+    return fwd::launch_dec_gemm(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act, false);
+  };
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
     half_t* kc = g->sk + (size_t)l * g->R * NT * d;
@@ -179,8 +183,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * m->t_pad;
     {
       ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
-      DG(fwd::launch_dec_gemm(st, g->x, d, L.qkv.w, nullptr, L.qkv.s1, L.qkv.cf, nullptr, 0, g->qkv, 3 * d, rows,
-                              3 * d, d, 0, false));
+      DG(lin(g->x, L.qkv, nullptr, g->qkv, 0));
     }
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0);
@@ -189,10 +192,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
-      DG(fwd::launch_dec_gemm(st, g->att, d, L.out.w, L.out.b, nullptr, nullptr, g->x, d, g->x, d, rows, d, d, 0,
-                              false));
-      DG(fwd::launch_dec_gemm(st, g->x, d, L.cq.w, nullptr, L.cq.s1, L.cq.cf, nullptr, 0, g->qc, d, rows, d, d, 0,
-                              false));
+      DG(lin(g->att, L.out, g->x, g->x, 0));
+      DG(lin(g->x, L.cq, nullptr, g->qc, 0));
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0);
@@ -206,12 +207,9 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 9.0 * d * d, 2.0 * 9.0 * d * d);
-      DG(fwd::launch_dec_gemm(st, g->att, d, L.cout.w, L.cout.b, nullptr, nullptr, g->x, d, g->x, d, rows, d, d, 0,
-                              false));
-      DG(fwd::launch_dec_gemm(st, g->x, d, L.ffn1.w, nullptr, L.ffn1.s1, L.ffn1.cf, nullptr, 0, g->ffn, 4 * d, rows,
-                              4 * d, d, 1, false));
-      DG(fwd::launch_dec_gemm(st, g->ffn, 4 * d, L.ffn2.w, L.ffn2.b, nullptr, nullptr, g->x, d, g->x, d, rows, d,
-                              4 * d, 0, false));
+      DG(lin(g->att, L.cout, g->x, g->x, 0));
+      DG(lin(g->x, L.ffn1, nullptr, g->ffn, 1));
+      DG(lin(g->ffn, L.ffn2, g->x, g->x, 0));
     }
   }
   if (s.need_logits || s.beam_tail) {
