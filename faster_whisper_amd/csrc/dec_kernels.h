@@ -24,6 +24,9 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
 int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
                     bool out_f32);
+int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
+                        const float* cf, const half_t* res, int ldr, half_t* out, int ldo, int R, int N, int K,
+                        int act);
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total);

@@ -208,6 +208,174 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(const half_t* __re
 }
 
 // ------------------------------------------------------------------------------------
+// Skinny GEMM, LDS-staged form (the per-layer decoder linears).
+//
+// rocprof showed the register-fragment form above spends its time in the texture-address unit:
+// an MFMA 16x16 fragment load puts 16 DIFFERENT rows on 16 consecutive lanes (16 cache lines per
+// quad, 64 B of each used), so the 80 activation rows re-read by every workgroup arrive at
+// ~20 B/clk/CU.  Here both operands go HBM/L2 -> LDS by direct DMA (global_load_lds, 16 B per lane,
+// full 640-byte row runs, no VGPR round trip) and the fragments are read from LDS, where the
+// scattered pattern is free (rows padded by one 16-byte slot => conflict-free ds_read_b128).
+//   * one workgroup = 16*NTW output columns x all K, K walked in slices of KQ = 8*KO through a
+//     2-slot LDS ring; slice q+1 is in flight while slice q is multiplied (counted vmcnt + raw
+//     s_barrier, never a full drain inside the loop);
+//   * the 4 waves own DIFFERENT activation row tiles (wave w: tiles w, w+4): no cross-wave
+//     reduction, the LayerNorm statistics of a row stay inside the wave that owns it.
+// ------------------------------------------------------------------------------------
+template <int MT, int NTW, int KO, int DEPTH, bool LNF, bool OUT_F32>
+__global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restrict__ x, int ldx,
+                                                           const half_t* __restrict__ W,
+                                                           const half_t* __restrict__ bias,
+                                                           const float* __restrict__ s1, const float* __restrict__ cf,
+                                                           const half_t* __restrict__ res, int ldr,
+                                                           void* __restrict__ outv, int ldo, int R, int N, int K,
+                                                           int act) {
+  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  constexpr int KQ = 8 * KO, STRIDE = KO + 1, NKS = KO / 4;   // k-steps of 32 per slice
+  constexpr int XROWS = MT * 16, XSLOTS = XROWS * STRIDE, XPAD = (XSLOTS + 255) / 256 * 256;
+  constexpr int WROWS = NTW * 16, WSLOTS = WROWS * STRIDE, WPAD = (WSLOTS + 255) / 256 * 256;
+  constexpr int NX = XPAD / 256, NW = WPAD / 256, NI = NX + NW;   // DMA instructions per wave per slice
+  constexpr int SLOT_BYTES = (XPAD + WPAD) * 16;
+  constexpr int MYT = (MT + 3) / 4;                               // row tiles per wave (max)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches below
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * (16 * NTW);
+  const int nq = K / KQ;
+  // blockIdx.y = activation row group (MT tiles each): short-N GEMMs are split over rows too so that
+  // all 256 CUs pull data (a CU sustains only ~50 GB/s of L2->LDS DMA)
+  const int row0 = blockIdx.y * (MT * 16);
+  R -= row0;
+  if (R <= 0) return;
+  x += (size_t)row0 * ldx;
+  if (res) res += (size_t)row0 * ldr;
+  if (OUT_F32) outv = reinterpret_cast<float*>(outv) + (size_t)row0 * ldo;
+  else outv = reinterpret_cast<half_t*>(outv) + (size_t)row0 * ldo;
+
+  auto issue = [&](int q, int slot) {
+    char* sbase = gl_smem + slot * SLOT_BYTES;
+    const int k0 = q * KQ;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int base = (wave + 4 * j) * 64;
+      int s = base + lane;
+      if (s > XSLOTS - 1) s = XSLOTS - 1;
+      int row = s / STRIDE, kk = s - row * STRIDE;
+      if (row > R - 1) row = R - 1;
+      if (kk > KO - 1) kk = KO - 1;
+      const half_t* src = x + (size_t)row * ldx + k0 + kk * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + base * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int base = (wave + 4 * j) * 64;
+      int s = base + lane;
+      if (s > WSLOTS - 1) s = WSLOTS - 1;
+      int row = s / STRIDE, kk = s - row * STRIDE;
+      if (kk > KO - 1) kk = KO - 1;
+      int wrow = n0 + row; if (wrow > N - 1) wrow = N - 1;
+      const half_t* src = W + (size_t)wrow * K + k0 + kk * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (XPAD + base) * 16), 16, 0,
+                                       0);
+    }
+  };
+
+  floatx4 acc[MYT][NTW];
+  float rs[MYT], rq[MYT];
+#pragma unroll
+  for (int a = 0; a < MYT; ++a) {
+    rs[a] = 0.f; rq[a] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[a][t] = floatx4{0, 0, 0, 0};
+  }
+
+  // DEPTH-slot ring: slices q+1 .. q+DEPTH-2 stay in flight while slice q is multiplied; the slot
+  // freed by slice q-1 is refilled right after the barrier that proves everyone is done with it.
+#pragma unroll
+  for (int sidx = 0; sidx < DEPTH - 1; ++sidx)
+    if (sidx < nq) issue(sidx, sidx);
+  for (int q = 0; q < nq; ++q) {
+    int pending = nq - 1 - q;
+    if (pending > DEPTH - 2) pending = DEPTH - 2;
+    if (pending <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else if (pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
+    __builtin_amdgcn_s_barrier();   // slice q has landed for every wave; slice q-1 is fully consumed
+    if (q + DEPTH - 1 < nq) issue(q + DEPTH - 1, (q + DEPTH - 1) % DEPTH);
+    const half8_t* xs = reinterpret_cast<const half8_t*>(gl_smem + (q % DEPTH) * SLOT_BYTES);
+    const half8_t* ws = xs + XPAD;
+    // all fragment reads of the slice are issued before the first MFMA needs them
+    half8_t wf[NKS][NTW];
+#pragma unroll
+    for (int j = 0; j < NKS; ++j)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) wf[j][t] = ws[(t * 16 + i) * STRIDE + j * 4 + g];
+#pragma unroll
+    for (int a = 0; a < MYT; ++a) {
+      const int mt = wave + 4 * a;
+      if (mt < MT) {
+        half8_t xf[NKS];
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) xf[j] = xs[(mt * 16 + i) * STRIDE + j * 4 + g];
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][t], xf[j], acc[a][t], 0, 0, 0);
+          if (LNF) {
+            const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h2 = {xf[j][2 * e], xf[j][2 * e + 1]};
+              rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
+              rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are complete
+  }
+  // ---- epilogue: each wave owns its rows outright ----
+#pragma unroll
+  for (int a = 0; a < MYT; ++a) {
+    const int mt = wave + 4 * a;
+    if (mt >= MT) continue;
+    const int row = mt * 16 + i;
+    float mu = 0.f, rstd = 1.f;
+    if (LNF) {
+      float sa = rs[a], sb = rq[a];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      mu = sa / (float)K;
+      const float var = fmaxf(sb / (float)K - mu * mu, 0.f);
+      rstd = rsqrtf(var + 1e-5f);
+    }
+    if (row >= R) continue;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int n = n0 + t * 16 + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) continue;
+        float tv = acc[a][t][e];
+        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
+        else if (bias) tv += (float)bias[n + e];
+        if (act == 1) tv = gelu_erf(tv);
+        if (res) tv += (float)res[(size_t)row * ldr + n + e];
+        if (OUT_F32)
+          reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = tv;
+        else
+          reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)tv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // K13: decoder self-attention for one (row, head), KV cache with slot indirection.
 // cache layout [slot][H][n_ctx][64].  The new K/V (position pos) are written to the row's
 // own slot; older positions are read from kvidx[row][p] (slot inside the chunk).
@@ -866,6 +1034,61 @@ static int gemm_k(hipStream_t st, int mt, int grid, const half_t* x, int ldx, co
   if (K % 256 == 0) return gemm_mt<NTW, 4, 8, false, LNF, F32>(ARGS);                   // long K: 8 waves, pipelined
   if (K / 128 <= 5) return gemm_mt<NTW, 5, 4, true, LNF, F32>(ARGS);                    // small K: 4 waves, one shot
   return gemm_mt<NTW, 3, 4, false, LNF, F32>(ARGS);
+#undef ARGS
+}
+
+template <int MT, int NTW, int KO, int DEPTH, bool LNF>
+static void lds_go(hipStream_t st, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+                   const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
+                   int K, int act) {
+  constexpr int XPAD = (MT * 16 * (KO + 1) + 255) / 256 * 256, WPAD = (NTW * 16 * (KO + 1) + 255) / 256 * 256;
+  static_assert(4 * ((XPAD + WPAD) / 256) <= 63 + 4, "vmcnt range");
+  const size_t lds = (size_t)DEPTH * (XPAD + WPAD) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int groups = ((R + 15) / 16 + MT - 1) / MT;
+  dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, false><<<dim3(grid, groups), 256, lds, st>>>(x, ldx, W, bias, s1, cf, res,
+                                                                                        ldr, out, ldo, R, N, K, act);
+}
+
+template <int NTW, int KO, int DEPTH, bool LNF>
+static int lds_mt(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+                  const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K,
+                  int act) {
+#define GO(MT) lds_go<MT, NTW, KO, DEPTH, LNF>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act)
+  switch (mt) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    case 5: GO(5); break;
+    default: return -1;
+  }
+#undef GO
+  return 0;
+}
+
+// LDS-staged skinny GEMM, fp16 output (the six per-layer decoder linears).
+int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
+                        const float* cf, const half_t* res, int ldr, half_t* out, int ldo, int R, int N, int K,
+                        int act) {
+  if (K % 128 != 0 || R < 1 || R > 80) return -1;
+  int mt = (R + 15) / 16;
+  if (N <= 2048 && mt > 2) mt = 2;   // short N: 2 row tiles per workgroup, row groups on grid.y
+  const bool lnf = s1 != nullptr;
+  const int ntw = (N <= 4096) ? 1 : 2;
+  const int grid = (N + 16 * ntw - 1) / (16 * ntw);
+#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act
+  if (K % 160 == 0) {   // slices of 160: ring of 4 (3 for the 32-column tile, LDS budget)
+    if (ntw == 1) return lnf ? lds_mt<1, 20, 4, true>(ARGS) : lds_mt<1, 20, 4, false>(ARGS);
+    return lnf ? lds_mt<2, 20, 3, true>(ARGS) : lds_mt<2, 20, 3, false>(ARGS);
+  }
+  if (ntw == 1) return lnf ? lds_mt<1, 16, 4, true>(ARGS) : lds_mt<1, 16, 4, false>(ARGS);
+  return lnf ? lds_mt<2, 16, 4, true>(ARGS) : lds_mt<2, 16, 4, false>(ARGS);
 #undef ARGS
 }
 

@@ -172,7 +172,10 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, rows, d, g->d_step, s.pos_fixed, s.P);
   }
   // one decoder linear: x[rows][K] -> out[rows][N]; LayerNorm-folded when L.s1 is set; in-place residual
+  static const bool use_lds_gemm = !(getenv("FWAMD_REG_GEMM") && getenv("FWAMD_REG_GEMM")[0] == '1');
   auto lin = [&](const half_t* xin, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
+    if (use_lds_gemm)
+      return fwd::launch_dec_gemm_lds(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act);
     return fwd::launch_dec_gemm(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act, false);
   };
   for (int l = 0; l < c.n_dec_layers; ++l) {
