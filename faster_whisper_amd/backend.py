@@ -169,10 +169,10 @@ def load_model_dir(path: str) -> Tuple[WhisperConfig, Dict[str, np.ndarray]]:
     cfg_path = os.path.join(path, "fwamd_config.json")
     if not os.path.isfile(cfg_path):
         if os.path.isfile(os.path.join(path, "model.bin")):
-            raise RuntimeError(
-                f"{path} is a CTranslate2 model directory; the model.bin reader is the next hot-path row "
-                "(SURVEY.md section 8f-1) and is not built yet. Convert with faster_whisper_amd.save_model_dir.")
-        raise RuntimeError(f"{path}: no fwamd_config.json found")
+            # a CTranslate2 converted directory (what the reference downloads, utils.py:91-97)
+            from .ct2_format import load_ct2_model_dir
+            return load_ct2_model_dir(path)
+        raise RuntimeError(f"{path}: neither fwamd_config.json nor model.bin found")
     with open(cfg_path) as f:
         j = json.load(f)
     j["suppress_begin"] = tuple(j.get("suppress_begin", ()))

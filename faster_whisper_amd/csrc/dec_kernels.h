@@ -17,6 +17,9 @@ struct GenDev {
   float rep_pen, lp_pow;
   int eot, no_ts, ts_begin;
   int n_sup_begin, sup_begin[8];
+  int sample;              // 1: draw the next token from softmax(logp / T) instead of arg-max / beam
+  float inv_temp;
+  unsigned seed_lo, seed_hi;
 };
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, int rows, int d,
@@ -31,7 +34,7 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total);
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
-                       int kmul, half_t* out, int B, int H, const int* done);
+                       int kmul, half_t* out, int B, int H, const int* done, int kv_div);
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
 void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
                            const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok);

@@ -479,15 +479,16 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const half_t* __res
                                                              const half_t* __restrict__ ck,
                                                              const half_t* __restrict__ cvt, int T, int t_pad,
                                                              int kmul, half_t* __restrict__ out,
-                                                             const int* __restrict__ done) {
+                                                             const int* __restrict__ done, int kv_div) {
   __shared__ float sm[4][16], sl[4][16];
   __shared__ float so[4][16][65];
   const int h = blockIdx.x, c = blockIdx.y;
   if (done && done[c]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const half_t* kbase = ck + (size_t)c * T * d + h * 64;
-  const half_t* vbase = cvt + ((size_t)c * d + h * 64) * t_pad;
+  const int ce = c / kv_div;   // encoder chunk whose K / V^T this decode chunk attends to
+  const half_t* kbase = ck + (size_t)ce * T * d + h * 64;
+  const half_t* vbase = cvt + ((size_t)ce * d + h * 64) * t_pad;
   half8_t qf[2];
   {
     if (j < kmul) {
@@ -646,6 +647,15 @@ static __device__ __forceinline__ PairMS pair_wave(PairMS a) {
 }
 
 #define LP_NV 56 /* values per thread kept in registers: V <= 56*1024 */
+// counter-based Gumbel noise: murmur3 finaliser of (seed, row, step, token) -> u in (0,1) -> -log(-log u).
+// oracle/whisper.py::_gumbel restates the same integer hash.
+static __device__ __forceinline__ float gumbel_noise(unsigned seed_lo, unsigned seed_hi, unsigned row, unsigned step,
+                                                     unsigned v) {
+  unsigned h = seed_lo ^ (row * 0x9E3779B9u) ^ (step * 0x85EBCA6Bu) ^ (v * 0xC2B2AE35u) ^ (seed_hi * 0x27D4EB2Fu);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return -logf(-logf(u));
+}
 __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::GenDev gp, float* __restrict__ logits,
                                                                         const uint8_t* __restrict__ sup_mask,
                                                                         const int* __restrict__ hist2,
@@ -656,9 +666,8 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
                                                                         int* __restrict__ cand_tok) {
   __shared__ PairMS red_t[LP_THREADS / 64], red_s[LP_THREADS / 64];
   __shared__ float sh_lse, sh_mask_text;
-  __shared__ float bv[LP_THREADS / 64];
+  __shared__ float bv[LP_THREADS / 64], braw[LP_THREADS / 64];
   __shared__ int bi[LP_THREADS / 64];
-  __shared__ float win_v;
   __shared__ int win_i;
   const int r = blockIdx.x;
   const int c = r / gp.K;
@@ -765,32 +774,40 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
     if (mask_text && v < tb) x = NEG;
     val[i] = (x == NEG) ? NEG : x - lse;
   }
-  // ---- top-C of cum + logp: C rounds of block arg-max (value desc, index asc) ----
+  // ---- top-C of cum + logp: C rounds of block arg-max (value desc, index asc).  Sampling mode
+  //      (Gumbel-max): one round on logp/T + Gumbel noise; the recorded score stays cum + logp. ----
   const float cum = cum2[(size_t)cur * gp.R + r];
-  const int C = 2 * gp.K;
+  const bool smp = gp.sample != 0;
+  const int C = smp ? 1 : 2 * gp.K;
   for (int cidx = 0; cidx < C; ++cidx) {
-    float v = NEG;
+    float v = NEG, vraw = NEG;
     int i = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < LP_NV; ++q)
-      if (val[q] > v) { v = val[q]; i = tid + q * LP_THREADS; }  // ascending index: ties keep the lowest
+    for (int q = 0; q < LP_NV; ++q) {
+      float key = val[q];
+      if (smp && key != NEG)
+        key = key * gp.inv_temp + gumbel_noise(gp.seed_lo, gp.seed_hi, (unsigned)r, (unsigned)step,
+                                               (unsigned)(tid + q * LP_THREADS));
+      if (key > v) { v = key; vraw = val[q]; i = tid + q * LP_THREADS; }  // ascending index: ties keep the lowest
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(v, o, 64);
+      const float orw = __shfl_xor(vraw, o, 64);
       const int oi = __shfl_xor(i, o, 64);
-      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+      if (ov > v || (ov == v && oi < i)) { v = ov; vraw = orw; i = oi; }
     }
-    if ((tid & 63) == 0) { bv[tid >> 6] = v; bi[tid >> 6] = i; }
+    if ((tid & 63) == 0) { bv[tid >> 6] = v; braw[tid >> 6] = vraw; bi[tid >> 6] = i; }
     __syncthreads();
     if (tid == 0) {
-      float wv = bv[0];
+      float wv = bv[0], wr = braw[0];
       int wi = bi[0];
       for (int q = 1; q < LP_THREADS / 64; ++q)
-        if (bv[q] > wv || (bv[q] == wv && bi[q] < wi)) { wv = bv[q]; wi = bi[q]; }
-      win_v = wv;
+        if (bv[q] > wv || (bv[q] == wv && bi[q] < wi)) { wv = bv[q]; wr = braw[q]; wi = bi[q]; }
       win_i = wi;
-      cand_val[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? NEG : cum + wv;
+      cand_val[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? NEG : cum + wr;
       cand_tok[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? 0 : wi;
+      if (smp) { cand_val[(size_t)r * 32 + 1] = NEG; cand_tok[(size_t)r * 32 + 1] = 0; }
     }
     __syncthreads();
     const int wi = win_i;
@@ -1120,8 +1137,8 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
-                       int kmul, half_t* out, int B, int H, const int* done) {
-  dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, t_pad, kmul, out, done);
+                       int kmul, half_t* out, int B, int H, const int* done, int kv_div) {
+  dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, t_pad, kmul, out, done, kv_div);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {

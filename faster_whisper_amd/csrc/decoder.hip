@@ -76,23 +76,24 @@ int gen_workspace_create(Model* m) {
   A(g->x, Rg * d); A(g->xn, Rg * d); A(g->qkv, Rg * 3 * d); A(g->att, Rg * d); A(g->qc, Rg * d);
   A(g->ffn, Rg * 4 * d);
   A(g->logits, Rg * c.n_vocab);
-  A(g->prompt_dev, NT * B);
+  A(g->prompt_dev, NT * Rg);
   A(g->cur_tok, Rg);
   A(g->hist2, 2 * R * NT);
   A(g->cum2, 2 * R);
   A(g->kvidx2, 2 * R * NT);
   A(g->cand_val, R * 32);
   A(g->cand_tok, R * 32);
-  A(g->done, B); A(g->n_done, 1); A(g->n_fin, B);
-  A(g->fin_tok, B * FIN_CAP * NT); A(g->fin_len, B * FIN_CAP);
-  A(g->fin_score, B * FIN_CAP); A(g->fin_cum, B * FIN_CAP);
+  // per-chunk state is sized by ROWS: random sampling runs every hypothesis as its own beam-1 chunk
+  A(g->done, Rg); A(g->n_done, 1); A(g->n_fin, Rg);
+  A(g->fin_tok, Rg * FIN_CAP * NT); A(g->fin_len, Rg * FIN_CAP);
+  A(g->fin_score, Rg * FIN_CAP); A(g->fin_cum, Rg * FIN_CAP);
   A(g->d_step, 1);
-  A(g->no_speech, B);
+  A(g->no_speech, Rg);
   A(g->sup_mask, (size_t)c.n_vocab);
-  A(g->zero_done, B);
+  A(g->zero_done, Rg);
 #undef A
   FW_HIP(hipMemset(g->cvt, 0, L * B * d * m->t_pad * sizeof(half_t)));
-  FW_HIP(hipMemset(g->zero_done, 0, B * sizeof(int)));
+  FW_HIP(hipMemset(g->zero_done, 0, Rg * sizeof(int)));
   FW_HIP(hipMemset(g->d_step, 0, sizeof(int)));
   const char* ng = getenv("FWAMD_NO_GRAPH");
   g->graphs_enabled = !(ng && ng[0] == '1');
@@ -145,6 +146,7 @@ struct StepCfg {
   int nospeech_rowmul; // > 0: run the no-speech kernel on rows b*rowmul after the logits GEMM
   bool beam_tail;      // logits rules + beam update + step advance
   const int* done;     // per-chunk done flags for cross-attn early exit
+  int kv_div = 1;      // decode chunks per encoder chunk (sampling: num_hypotheses)
   // align extras
   const int* sel_heads_dev = nullptr;   // [n_sel_total] head ids, grouped per layer
   const int* sel_layer_off = nullptr;   // host: [L+1] offsets into sel_heads
@@ -206,7 +208,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * s.B * (double)T * d);
-      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, m->t_pad, s.kmul, g->att, s.B, H, s.done);
+      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, m->t_pad, s.kmul, g->att, s.B, H, s.done, s.kv_div);
     }
     {
       ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 9.0 * d * d, 2.0 * 9.0 * d * d);
@@ -268,10 +270,18 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
   const int K = o->beam_size;
   FW_CHECK_ARG(K >= 1 && K <= m->max_beam, "beam_size %d not in [1, max_beam=%d]", K, m->max_beam);
-  FW_CHECK_ARG(o->num_hypotheses >= 1 && o->num_hypotheses <= std::max(K, 1),
-               "num_hypotheses %d must be in [1, beam_size]", o->num_hypotheses);
-  FW_CHECK_ARG(!(K == 1 && o->sampling_topk != 1),
-               "random sampling (sampling_topk != 1) belongs to the sequential fallback path, which is not built yet");
+  // random sampling (the sequential path's temperature fallback, transcribe.py:1433-1439): beam_size 1,
+  // sampling_topk 0 (whole distribution), num_hypotheses = best_of independent samples per chunk
+  const bool sampling = (K == 1 && o->sampling_topk != 1);
+  if (sampling) {
+    FW_CHECK_ARG(o->sampling_topk == 0, "sampling_topk must be 1 (greedy) or 0 (sample the whole distribution)");
+    FW_CHECK_ARG(o->sampling_temperature > 0.f, "sampling_temperature must be positive");
+    FW_CHECK_ARG(o->num_hypotheses >= 1 && B * o->num_hypotheses <= g->R,
+                 "batch x num_hypotheses = %d exceeds the %d decoder rows of this model", B * o->num_hypotheses, g->R);
+  } else {
+    FW_CHECK_ARG(o->num_hypotheses >= 1 && o->num_hypotheses <= std::max(K, 1),
+                 "num_hypotheses %d must be in [1, beam_size]", o->num_hypotheses);
+  }
   FW_CHECK_ARG(o->patience > 0.f, "patience must be positive");
   FW_CHECK_ARG(o->max_length >= 1, "max_length must be positive");
   const int P = prompt_offsets[1] - prompt_offsets[0];
@@ -295,9 +305,15 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   int rc;
   if ((rc = ensure_cross_kv(m, enc))) return rc;
 
+  const int kv_div = sampling ? nh : 1;   // decode chunks per encoder chunk
+  const int Bx = B * kv_div;
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
-  gp.B = B; gp.K = K; gp.R = B * K; gp.P = P; gp.budget = budget;
+  gp.B = Bx; gp.K = K; gp.R = Bx * K; gp.P = P; gp.budget = budget;
+  gp.sample = sampling ? 1 : 0;
+  gp.inv_temp = sampling ? 1.0f / o->sampling_temperature : 1.0f;
+  gp.seed_lo = (unsigned)(o->seed & 0xffffffffu);
+  gp.seed_hi = (unsigned)(o->seed >> 32);
   gp.max_fin = std::max(1, (int)lroundf((float)K * o->patience));
   if (gp.max_fin > FIN_CAP - K) gp.max_fin = FIN_CAP - K;
   gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
@@ -323,11 +339,11 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   FW_HIP(hipMemsetAsync(g->hist2, 0, 2 * R * NT * sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * R * NT, st));
   FW_HIP(hipMemsetAsync(g->cum2, 0, 2 * R * sizeof(float), st));
-  FW_HIP(hipMemsetAsync(g->done, 0, g->B * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->done, 0, R * sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->n_done, 0, sizeof(int), st));
-  FW_HIP(hipMemsetAsync(g->n_fin, 0, g->B * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->n_fin, 0, R * sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
-  FW_HIP(hipMemsetAsync(g->no_speech, 0, g->B * sizeof(float), st));
+  FW_HIP(hipMemsetAsync(g->no_speech, 0, R * sizeof(float), st));
   {
     std::vector<uint8_t> mask(c.n_vocab, 0);
     for (int i = 0; i < o->n_suppress_tokens; ++i) {
@@ -338,11 +354,11 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     FW_HIP(hipStreamSynchronize(st));  // mask is a stack-local buffer
   }
   // prompt tokens transposed to [pos][b]; first-step tokens replicated per beam
-  std::vector<int> ptok((size_t)P * B), first((size_t)B * K);
-  for (int b = 0; b < B; ++b)
-    for (int p = 0; p < P; ++p) ptok[(size_t)p * B + b] = prompts[prompt_offsets[b] + p];
-  for (int b = 0; b < B; ++b)
-    for (int k = 0; k < K; ++k) first[(size_t)b * K + k] = prompts[prompt_offsets[b] + P - 1];
+  std::vector<int> ptok((size_t)P * Bx), first((size_t)Bx * K);
+  for (int bx = 0; bx < Bx; ++bx)
+    for (int p = 0; p < P; ++p) ptok[(size_t)p * Bx + bx] = prompts[prompt_offsets[bx / kv_div] + p];
+  for (int bx = 0; bx < Bx; ++bx)
+    for (int k = 0; k < K; ++k) first[(size_t)bx * K + k] = prompts[prompt_offsets[bx / kv_div] + P - 1];
   FW_HIP(hipMemcpyAsync(g->prompt_dev, ptok.data(), ptok.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FW_HIP(hipMemcpyAsync(g->cur_tok, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FW_HIP(hipStreamSynchronize(st));
@@ -350,7 +366,8 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   // ---- prompt forward (all but the last token): B rows, beam slot 0 of every chunk ----
   for (int pos = 0; pos < P - 1; ++pos) {
     StepCfg s;
-    s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = pos; s.P = P; s.tok = g->prompt_dev + (size_t)pos * B;
+    s.rows = Bx; s.kmul = 1; s.B = Bx; s.pos_fixed = pos; s.P = P; s.tok = g->prompt_dev + (size_t)pos * Bx;
+    s.kv_div = kv_div;
     s.need_logits = (pos == sot_pos) && o->return_no_speech_prob;
     s.nospeech_rowmul = s.need_logits ? 1 : 0;
     s.beam_tail = false;
@@ -363,7 +380,8 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   if (budget > 0) {
     // ---- step 0 (eager): last prompt token on all R rows; beams are identical copies ----
     StepCfg s;
-    s.rows = B * K; s.kmul = K; s.B = B; s.pos_fixed = -1; s.P = P; s.tok = g->cur_tok;
+    s.rows = Bx * K; s.kmul = K; s.B = Bx; s.pos_fixed = -1; s.P = P; s.tok = g->cur_tok;
+    s.kv_div = kv_div;
     s.need_logits = true;
     s.nospeech_rowmul = (sot_pos == P - 1 && o->return_no_speech_prob) ? K : 0;
     s.beam_tail = true;
@@ -408,7 +426,7 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
       steps_done += burst;
       FW_HIP(hipMemcpyAsync(&n_done_host, g->n_done, sizeof(int), hipMemcpyDeviceToHost, st));
       FW_HIP(hipStreamSynchronize(st));
-      if (n_done_host >= B) break;
+      if (n_done_host >= Bx) break;
     }
   }
   FW_HIP(hipStreamSynchronize(st));
@@ -416,28 +434,32 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   prof_collect(m);
 
   // ---- finalize on the host: best num_hypotheses by normalised score (stable) ----
-  std::vector<int> n_fin(B), fin_len((size_t)B * FIN_CAP);
-  std::vector<float> fin_score((size_t)B * FIN_CAP), nsp(B);
-  std::vector<int> fin_tok((size_t)B * FIN_CAP * NT);
-  FW_HIP(hipMemcpy(n_fin.data(), g->n_fin, B * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> n_fin(Bx), fin_len((size_t)Bx * FIN_CAP);
+  std::vector<float> fin_score((size_t)Bx * FIN_CAP), nsp(Bx);
+  std::vector<int> fin_tok((size_t)Bx * FIN_CAP * NT);
+  FW_HIP(hipMemcpy(n_fin.data(), g->n_fin, Bx * sizeof(int), hipMemcpyDeviceToHost));
   FW_HIP(hipMemcpy(fin_len.data(), g->fin_len, fin_len.size() * sizeof(int), hipMemcpyDeviceToHost));
   FW_HIP(hipMemcpy(fin_score.data(), g->fin_score, fin_score.size() * sizeof(float), hipMemcpyDeviceToHost));
   FW_HIP(hipMemcpy(fin_tok.data(), g->fin_tok, fin_tok.size() * sizeof(int), hipMemcpyDeviceToHost));
-  FW_HIP(hipMemcpy(nsp.data(), g->no_speech, B * sizeof(float), hipMemcpyDeviceToHost));
+  FW_HIP(hipMemcpy(nsp.data(), g->no_speech, Bx * sizeof(float), hipMemcpyDeviceToHost));
   for (int b = 0; b < B; ++b) {
-    if (o->return_no_speech_prob) out_no_speech[b] = nsp[b];
-    std::vector<int> order(n_fin[b]);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int bb) {
-      return fin_score[(size_t)b * FIN_CAP + a] > fin_score[(size_t)b * FIN_CAP + bb];
+    if (o->return_no_speech_prob) out_no_speech[b] = nsp[(size_t)b * kv_div];
+    // candidate hypotheses of encoder chunk b: (decode chunk, finished index)
+    std::vector<std::pair<int, int>> hyps;
+    for (int j = 0; j < kv_div; ++j) {
+      const int bx = b * kv_div + j;
+      for (int f = 0; f < n_fin[bx]; ++f) hyps.push_back({bx, f});
+    }
+    std::stable_sort(hyps.begin(), hyps.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& bb) {
+      return fin_score[(size_t)a.first * FIN_CAP + a.second] > fin_score[(size_t)bb.first * FIN_CAP + bb.second];
     });
-    for (int h = 0; h < nh && h < (int)order.size(); ++h) {
-      const int f = order[h];
-      int len = fin_len[(size_t)b * FIN_CAP + f];
+    for (int h = 0; h < nh && h < (int)hyps.size(); ++h) {
+      const size_t f = (size_t)hyps[h].first * FIN_CAP + hyps[h].second;
+      int len = fin_len[f];
       if (len > ml) len = ml;
       out_lens[b * nh + h] = len;
-      if (o->return_scores) out_scores[b * nh + h] = fin_score[(size_t)b * FIN_CAP + f];
-      memcpy(out_ids + ((size_t)b * nh + h) * ml, &fin_tok[((size_t)b * FIN_CAP + f) * NT], (size_t)len * sizeof(int));
+      if (o->return_scores) out_scores[b * nh + h] = fin_score[f];
+      memcpy(out_ids + ((size_t)b * nh + h) * ml, &fin_tok[f * NT], (size_t)len * sizeof(int));
     }
   }
   return FW_OK;

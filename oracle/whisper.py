@@ -246,7 +246,8 @@ class OracleWhisper:
                  num_hypotheses=1, length_penalty=1.0, repetition_penalty=1.0, no_repeat_ngram_size=0,
                  max_length=448, return_scores=True, return_no_speech_prob=True, max_initial_timestamp_index=50,
                  suppress_blank=True, suppress_tokens=None, sampling_topk=1, sampling_temperature=1.0,
-                 min_new_tokens=0, force_tokens: Optional[Sequence[Sequence[int]]] = None) -> List[GenResult]:
+                 min_new_tokens=0, force_tokens: Optional[Sequence[Sequence[int]]] = None,
+                 seed: int = 0) -> List[GenResult]:
         """CTranslate2 Whisper.generate semantics (greedy for beam_size == 1, beam search otherwise).
         force_tokens: teacher forcing for margin diagnostics (greedy only): the chosen token at each
         step is taken from this list instead of the argmax."""
@@ -258,8 +259,23 @@ class OracleWhisper:
             if ids:
                 sup = np.asarray(sorted(set(ids)), dtype=np.int64)
         out = []
+        sampling = beam_size == 1 and sampling_topk != 1
         with torch.no_grad():
             for b, prompt in enumerate(prompts):
+                if sampling:
+                    # random sampling = num_hypotheses independent beam-1 chunks (rows b*nh + j), best first
+                    hyps = []
+                    for j in range(num_hypotheses):
+                        smp = (seed, b * num_hypotheses + j, 1.0 / sampling_temperature)
+                        r = self._generate_one(enc_t[b:b + 1], list(prompt), 1, patience, 1, length_penalty,
+                                               repetition_penalty, no_repeat_ngram_size, max_length,
+                                               max_initial_timestamp_index, suppress_blank, sup, min_new_tokens,
+                                               None, sample=smp)
+                        hyps.append(r)
+                    order = sorted(range(len(hyps)), key=lambda t: -hyps[t].scores[0])
+                    out.append(GenResult([hyps[t].sequences_ids[0] for t in order], [hyps[t].scores[0] for t in order],
+                                         hyps[0].no_speech_prob))
+                    continue
                 out.append(self._generate_one(enc_t[b:b + 1], list(prompt), beam_size, patience, num_hypotheses,
                                               length_penalty, repetition_penalty, no_repeat_ngram_size, max_length,
                                               max_initial_timestamp_index, suppress_blank, sup, min_new_tokens,
@@ -267,7 +283,7 @@ class OracleWhisper:
         return out
 
     def _generate_one(self, enc1, prompt, K, patience, num_hyp, lp_pow, rep_pen, ngram, max_length, mits,
-                      suppress_blank, sup, min_new, forced):
+                      suppress_blank, sup, min_new, forced, sample=None):
         c = self.cfg
         P = len(prompt)
         budget = max_new_tokens(max_length, P)
@@ -294,7 +310,7 @@ class OracleWhisper:
             return self._process_logits(lg_row, gen, with_ts, sup, suppress_blank, mits, rep_pen, ngram, min_new)
 
         if K == 1:
-            return self._greedy(cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced)
+            return self._greedy(cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced, sample)
 
         # ---------------- beam search [CT2-ext: BeamSearch::search in src/decoding.cc] ----------------
         ckv = [(k.expand(K, -1, -1, -1), v.expand(K, -1, -1, -1)) for k, v in ckv1]
@@ -351,7 +367,7 @@ class OracleWhisper:
         best = finished[:max(1, num_hyp)]
         return GenResult([t[1] for t in best], [float(t[0]) for t in best], no_speech)
 
-    def _greedy(self, cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced):
+    def _greedy(self, cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced, sample=None):
         c = self.cfg
         gen, margins = [], []
         cum = np.float32(0.0)
@@ -359,9 +375,16 @@ class OracleWhisper:
         ended = False
         while step < budget:
             lp = proc(logits[0], gen)
-            order = _topk_stable(lp, 2)
+            if sample is not None:   # Gumbel-max draw from softmax(lp / T); the score keeps the plain lp
+                seed, row, inv_t = sample
+                key = np.where(np.isfinite(lp), lp * np.float32(inv_t) + _gumbel(seed, row, step, lp.shape[0]),
+                               np.float32(-np.inf)).astype(np.float32)
+                order = _topk_stable(key, 2)
+                margins.append(float(key[order[0]] - key[order[1]]))
+            else:
+                order = _topk_stable(lp, 2)
+                margins.append(float(lp[order[0]] - lp[order[1]]))
             tok = int(order[0])
-            margins.append(float(lp[order[0]] - lp[order[1]]))
             if forced is not None and step < len(forced):
                 tok = int(forced[step])
             cum = np.float32(cum + lp[tok])
@@ -449,6 +472,22 @@ def _logsumexp(x: np.ndarray) -> np.float32:
     if not np.isfinite(m):
         return np.float32(-np.inf)
     return np.float32(m + np.log(np.exp((x - m).astype(np.float32)).sum(dtype=np.float32)))
+
+
+def _gumbel(seed: int, row: int, step: int, n: int) -> np.ndarray:
+    """counter-based Gumbel noise, same integer hash as dec_kernels.hip::gumbel_noise"""
+    M = np.uint64(0xFFFFFFFF)
+    v = np.arange(n, dtype=np.uint64)
+    h = (np.uint64(seed & 0xFFFFFFFF) ^ ((np.uint64(row) * np.uint64(0x9E3779B9)) & M)
+         ^ ((np.uint64(step) * np.uint64(0x85EBCA6B)) & M) ^ ((v * np.uint64(0xC2B2AE35)) & M)
+         ^ ((np.uint64((seed >> 32) & 0xFFFFFFFF) * np.uint64(0x27D4EB2F)) & M))
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & M
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & M
+    h ^= h >> np.uint64(16)
+    u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return (-np.log(-np.log(u))).astype(np.float32)
 
 
 def _topk_stable(x: np.ndarray, k: int) -> np.ndarray:

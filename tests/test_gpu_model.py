@@ -148,6 +148,39 @@ def test_generate_eot_and_early_finish(setup):
             print(f"[{cfg.name}] budget-3 beam={beam}: {g.sequences_ids[0]} vs {r.sequences_ids[0]}")
 
 
+def test_generate_sampling(setup):
+    """temperature fallback of the sequential path (transcribe.py:1433-1439): beam_size=1, sampling_topk=0,
+    num_hypotheses=best_of.  The engine and the oracle share the counter-based Gumbel hash, so the same
+    seed must give the same samples (up to float noise at near-ties of the perturbed keys)."""
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    prompt = _prompt(cfg)
+    kw = dict(beam_size=1, num_hypotheses=5, sampling_topk=0, sampling_temperature=0.8, max_length=len(prompt) + 12,
+              suppress_tokens=_suppress(cfg), seed=1234)
+    got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+    ref = oracle.generate(enc_np, [prompt] * 3, **kw)
+    same = total = 0
+    for g, r in zip(got, ref):
+        assert len(g.sequences_ids) == 5 and all(len(s) == 12 for s in g.sequences_ids)
+        assert g.scores == sorted(g.scores, reverse=True)
+        assert len({tuple(s) for s in g.sequences_ids}) >= 4          # samples differ from each other
+        gs = {tuple(s): sc for s, sc in zip(g.sequences_ids, g.scores)}
+        for s, sc in zip(r.sequences_ids, r.scores):
+            total += 1
+            if tuple(s) in gs:
+                same += 1
+                assert abs(gs[tuple(s)] - sc) < 2e-3 * max(1.0, abs(sc))
+    print(f"[{cfg.name}] sampling: {same}/{total} sampled sequences identical to the oracle's")
+    assert same >= int(0.8 * total)
+    # a different seed gives different samples; greedy is unaffected by the seed
+    other = model.generate(enc, [prompt] * 3, **dict(kw, seed=99))
+    assert other[0].sequences_ids != got[0].sequences_ids
+    with pytest.raises(ValueError):
+        model.generate(enc, [prompt] * 3, beam_size=1, sampling_topk=7)
+
+
 def test_generate_argument_errors(setup):
     from faster_whisper_amd.backend import StorageView
     cfg, model, oracle, feats = setup
