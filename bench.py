@@ -42,13 +42,13 @@ def synth_chunks(n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=100)
-    ap.add_argument("--workers", type=int, default=4,
+    ap.add_argument("--workers", type=int, default=8,
                     help="batches kept in flight per GPU (worker replicas sharing the weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -176,6 +176,7 @@ def main():
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
             roof["kernel"] = name
+            roof["traffic"] = pmc_traffic(name)
             roof["kernel_ms_per_step"] = round(dom["ms"], 3)
             roof["launch_groups_per_step"] = dom["launches"]
             out["roofline"] = roof
@@ -198,6 +199,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "void gemm_f16_kernel<false>",
+               "enc_attn": "attn_enc_kernel"}
+
+
+def pmc_traffic(family):
+    """HBM read bytes per launch of the family's kernel from the committed rocprofv3 --pmc FETCH_SIZE pass
+    (profiles/r01_pmc_fetch.json, x2 gfx950 correction already applied by profiles/parse_pmc.py); null if
+    that kernel was not measured."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")
+    if not os.path.exists(path) or family not in _PMC_KERNEL:
+        return None
+    with open(path) as f:
+        j = json.load(f)
+    for k, v in j.items():
+        if _PMC_KERNEL[family] in k or k in _PMC_KERNEL[family]:
+            b = v.get("hbm_read_bytes_per_launch_corrected")
+            return None if b is None else {"hbm_read_bytes_per_launch": round(b), "source": "profiles/r01_pmc_fetch.json"}
+    return None
 
 
 def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):

@@ -187,7 +187,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const half_t* ck = g->ck + (size_t)l * g->B * T * d;
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * m->t_pad;
     {
-      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
+      ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
       DG(lin(g->x, L.qkv, nullptr, g->qkv, 0));
     }
     {
@@ -196,7 +196,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
                             s.pos_fixed, s.P, gp.R);
     }
     {
-      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
+      ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
       DG(lin(g->att, L.out, g->x, g->x, 0));
       DG(lin(g->x, L.cq, nullptr, g->qc, 0));
     }
@@ -211,9 +211,15 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
       fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, m->t_pad, s.kmul, g->att, s.B, H, s.done, s.kv_div);
     }
     {
-      ProfScope ps(m, PF_DEC_GEMM, 2.0 * rows * 9.0 * d * d, 2.0 * 9.0 * d * d);
+      ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d);
       DG(lin(g->att, L.cout, g->x, g->x, 0));
+    }
+    {
+      ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
       DG(lin(g->x, L.ffn1, nullptr, g->ffn, 1));
+    }
+    {
+      ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
       DG(lin(g->ffn, L.ffn2, g->x, g->x, 0));
     }
   }

@@ -73,7 +73,8 @@ struct DecLayerW { LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };  // qkv, c
 
 enum ProfFamily {
   PF_LOGMEL = 0, PF_ENC_GEMM, PF_ENC_ATTN, PF_ENC_LN, PF_CROSS_KV_GEMM,
-  PF_DEC_GEMM, PF_DEC_SELF_ATTN, PF_DEC_CROSS_ATTN, PF_DEC_LOGITS, PF_DEC_SAMPLE, PF_DEC_MISC, PF_COUNT
+  PF_DEC_GEMM_QKV, PF_DEC_GEMM_DXD, PF_DEC_GEMM_FFN1, PF_DEC_GEMM_FFN2,
+  PF_DEC_SELF_ATTN, PF_DEC_CROSS_ATTN, PF_DEC_LOGITS, PF_DEC_SAMPLE, PF_DEC_MISC, PF_COUNT
 };
 
 struct ProfAcc {

@@ -39,8 +39,8 @@ int dev_alloc(void** p, size_t bytes) {
 
 // ---------------------------------------------------------------- profiling
 static const char* kProfNames[PF_COUNT] = {
-    "logmel", "enc_gemm", "enc_attn", "enc_layernorm", "cross_kv_gemm", "dec_gemm",
-    "dec_self_attn", "dec_cross_attn", "dec_logits", "dec_sample", "dec_misc"};
+    "logmel", "enc_gemm", "enc_attn", "enc_layernorm", "cross_kv_gemm", "dec_gemm_qkv", "dec_gemm_dxd",
+    "dec_gemm_ffn1", "dec_gemm_ffn2", "dec_self_attn", "dec_cross_attn", "dec_logits", "dec_sample", "dec_misc"};
 
 static hipEvent_t ev_get(Model* m) {
   if (!m->ev_pool.empty()) {

@@ -10,13 +10,13 @@
 // gfx950 mapping
 //  * 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
 //    v_mfma_f32_32x32x16_f16 (64 accumulator VGPRs).
-//  * global -> VGPR (16 B/lane, coalesced 128 B rows) -> LDS (ds_write_b128) ->
-//    MFMA fragments (ds_read_b128). LDS rows are 128 B; the 16-byte chunk index is
-//    XOR-swizzled with (row>>1)&7, which makes every ds_read_b128 lane group
+//  * global -> LDS by direct DMA (global_load_lds, 16 B/lane, coalesced 128 B rows, no VGPR
+//    round trip) -> MFMA fragments (ds_read_b128). LDS rows are 128 B; the 16-byte chunk
+//    index is XOR-swizzled with (row>>1)&7 (applied to the DMA source address, the LDS
+//    image itself is lane-linear), which makes every ds_read_b128 lane group
 //    conflict-free (MI355X_MICROARCH.md LDS table).
-//  * double-buffered LDS, ONE barrier per K tile; the next tile's global loads are
-//    issued before the MFMA block and written to LDS after it (issue-early /
-//    write-late), so HBM/L2 latency hides under the matrix pipe.
+//  * double-buffered LDS, ONE barrier per K tile; the next tile's DMA is issued right
+//    after that barrier and lands while the current tile is multiplied.
 //  * normal mode computes D = W_tile * A_tile^T so that each lane ends up with four
 //    consecutive n of one row m -> 8-byte stores; TRANS mode computes D = A_tile *
 //    W_tile^T, each lane holds four consecutive m of one column n, and the tile is
@@ -53,34 +53,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
   const int m0 = mt * GB_M, n0 = nt * GB_N;
 
   const half_t* Ab = p.A + (size_t)z * p.a_bstride;
-  // staging map: thread -> (row r0 + 32*i, 16-byte chunk c) of the [128][64] tile
-  const int c = tid & 7, r0 = tid >> 3;
+  // staging: direct HBM/L2 -> LDS DMA (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write
+  // pass).  A wave instruction fills 64 consecutive 16-byte LDS slots = 8 tile rows; the LDS image must
+  // stay lane-linear, so the XOR swizzle is applied to the SOURCE address: LDS slot (row, c') receives
+  // global chunk c = c' ^ ((row >> 1) & 7)  (the fragment reads below apply the same involution).
+  const int wuni = __builtin_amdgcn_readfirstlane(wave);
   const half_t* gA[4];
   const half_t* gW[4];
-  int soff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = r0 + 32 * i;
+    const int row = (i * 4 + wuni) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
     int am = m0 + row; if (am > p.M - 1) am = p.M - 1;
     int wn_ = n0 + row; if (wn_ > p.N - 1) wn_ = p.N - 1;
     gA[i] = Ab + (size_t)am * p.lda + c * 8;
     gW[i] = p.W + (size_t)wn_ * p.ldw + c * 8;
-    soff[i] = row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
   }
-  intx4 ra[4], rw[4];
   const int nk = p.K / GB_K;
-
+  auto stage = [&](int kt, int buf) {
+    const int koff = kt * GB_K;
+    char* dA = reinterpret_cast<char*>(sA + buf * GB_TILE_HALVES);
+    char* dW = reinterpret_cast<char*>(sW + buf * GB_TILE_HALVES);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const intx4*>(gA[i]);
-    rw[i] = *reinterpret_cast<const intx4*>(gW[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<intx4*>(sA + soff[i]) = ra[i];
-    *reinterpret_cast<intx4*>(sW + soff[i]) = rw[i];
-  }
-  __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(dA + (i * 4 + wuni) * 1024), 16, 0,
+                                       0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(dW + (i * 4 + wuni) * 1024), 16, 0,
+                                       0);
+    }
+  };
+  stage(0, 0);
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -98,15 +102,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      const int koff = (kt + 1) * GB_K;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const intx4*>(gA[i] + koff);
-        rw[i] = *reinterpret_cast<const intx4*>(gW[i] + koff);
-      }
-    }
+    // tile kt has landed (this wave's DMAs drained, then the barrier covers the other waves'); the same
+    // barrier proves every wave is done reading buffer cur^1, which the next tile's DMA overwrites while
+    // this tile is multiplied.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
     const half_t* cA = sA + cur * GB_TILE_HALVES;
     const half_t* cW = sW + cur * GB_TILE_HALVES;
 #pragma unroll
@@ -128,16 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (more) {
-      half_t* nA = sA + (cur ^ 1) * GB_TILE_HALVES;
-      half_t* nW = sW + (cur ^ 1) * GB_TILE_HALVES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<intx4*>(nA + soff[i]) = ra[i];
-        *reinterpret_cast<intx4*>(nW + soff[i]) = rw[i];
-      }
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
   // ---------------------------------- epilogue ----------------------------------
