@@ -30,6 +30,9 @@ int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, c
 int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, int R, int N, int K,
                         int act);
+int launch_dec_gemm_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq, const float* w_scale,
+                       const half_t* bias, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
+                       bool out_f32);
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total);

@@ -12,6 +12,7 @@
 // slots through a [row][position] -> slot table instead.
 #include "common.h"
 #include "dec_kernels.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------
 // K12: token + learned-position embedding  x[r] = E[tok[r]] + pos[p]
@@ -222,16 +223,20 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(const half_t* __re
 //   * the 4 waves own DIFFERENT activation row tiles (wave w: tiles w, w+4): no cross-wave
 //     reduction, the LayerNorm statistics of a row stay inside the wave that owns it.
 // ------------------------------------------------------------------------------------
-template <int MT, int NTW, int KO, int DEPTH, bool LNF, bool OUT_F32>
+// I8 (int8_float16, K25): x and W are int8 with per-row de-quantisation scales (x_scale[r], w_scale[n]);
+// a 16-byte piece then holds 16 elements, v_mfma_i32_16x16x64_i8 accumulates in int32.
+template <int MT, int NTW, int KO, int DEPTH, bool LNF, bool OUT_F32, bool I8>
 __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restrict__ x, int ldx,
                                                            const half_t* __restrict__ W,
                                                            const half_t* __restrict__ bias,
                                                            const float* __restrict__ s1, const float* __restrict__ cf,
                                                            const half_t* __restrict__ res, int ldr,
                                                            void* __restrict__ outv, int ldo, int R, int N, int K,
-                                                           int act) {
+                                                           int act, const float* __restrict__ x_scale,
+                                                           const float* __restrict__ w_scale) {
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
-  constexpr int KQ = 8 * KO, STRIDE = KO + 1, NKS = KO / 4;   // k-steps of 32 per slice
+  constexpr int ES = I8 ? 1 : 2, EPP = 16 / ES;              // element size, elements per 16-byte piece
+  constexpr int KQ = EPP * KO, STRIDE = KO + 1, NKS = KO / 4;  // MFMA k-steps per slice
   constexpr int XROWS = MT * 16, XSLOTS = XROWS * STRIDE, XPAD = (XSLOTS + 255) / 256 * 256;
   constexpr int WROWS = NTW * 16, WSLOTS = WROWS * STRIDE, WPAD = (WSLOTS + 255) / 256 * 256;
   constexpr int NX = XPAD / 256, NW = WPAD / 256, NI = NX + NW;   // DMA instructions per wave per slice
@@ -247,7 +252,9 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
   const int row0 = blockIdx.y * (MT * 16);
   R -= row0;
   if (R <= 0) return;
-  x += (size_t)row0 * ldx;
+  const char* xb = reinterpret_cast<const char*>(x) + (size_t)row0 * ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(W);
+  if (I8) x_scale += row0;
   if (res) res += (size_t)row0 * ldr;
   if (OUT_F32) outv = reinterpret_cast<float*>(outv) + (size_t)row0 * ldo;
   else outv = reinterpret_cast<half_t*>(outv) + (size_t)row0 * ldo;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
       int row = s / STRIDE, kk = s - row * STRIDE;
       if (row > R - 1) row = R - 1;
       if (kk > KO - 1) kk = KO - 1;
-      const half_t* src = x + (size_t)row * ldx + k0 + kk * 8;
+      const char* src = xb + ((size_t)row * ldx + k0 + kk * EPP) * ES;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + base * 16), 16, 0, 0);
     }
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
       int row = s / STRIDE, kk = s - row * STRIDE;
       if (kk > KO - 1) kk = KO - 1;
       int wrow = n0 + row; if (wrow > N - 1) wrow = N - 1;
-      const half_t* src = W + (size_t)wrow * K + k0 + kk * 8;
+      const char* src = Wb + ((size_t)wrow * K + k0 + kk * EPP) * ES;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (XPAD + base) * 16), 16, 0,
                                        0);
@@ -283,12 +290,13 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
   };
 
   floatx4 acc[MYT][NTW];
+  intx4 acci[MYT][NTW];
   float rs[MYT], rq[MYT];
 #pragma unroll
   for (int a = 0; a < MYT; ++a) {
     rs[a] = 0.f; rq[a] = 0.f;
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[a][t] = floatx4{0, 0, 0, 0};
+    for (int t = 0; t < NTW; ++t) { acc[a][t] = floatx4{0, 0, 0, 0}; acci[a][t] = intx4{0, 0, 0, 0}; }
   }
 
   // DEPTH-slot ring: slices q+1 .. q+DEPTH-2 stay in flight while slice q is multiplied; the slot
@@ -323,8 +331,13 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
 #pragma unroll
         for (int j = 0; j < NKS; ++j) {
 #pragma unroll
-          for (int t = 0; t < NTW; ++t)
-            acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][t], xf[j], acc[a][t], 0, 0, 0);
+          for (int t = 0; t < NTW; ++t) {
+            if (I8)
+              acci[a][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(intx4, wf[j][t]),
+                                                               __builtin_bit_cast(intx4, xf[j]), acci[a][t], 0, 0, 0);
+            else
+              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][t], xf[j], acc[a][t], 0, 0, 0);
+          }
           if (LNF) {
             const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
@@ -355,13 +368,14 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
       rstd = rsqrtf(var + 1e-5f);
     }
     if (row >= R) continue;
+    const float sxr = I8 ? x_scale[row] : 1.f;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int n = n0 + t * 16 + 4 * g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (n + e >= N) continue;
-        float tv = acc[a][t][e];
+        float tv = I8 ? (float)acci[a][t][e] * sxr * w_scale[n + e] : acc[a][t][e];
         if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
         else if (bias) tv += (float)bias[n + e];
         if (act == 1) tv = gelu_erf(tv);
@@ -475,19 +489,20 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
 //   O^T tile = V^T x P^T        (A = 16 bytes of a time-contiguous V^T row)
 // 4 waves stride over 32-key groups with an online softmax each; merged through LDS.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
+#define CA_WAVES 8
+__global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
                                                              const half_t* __restrict__ ck,
                                                              const half_t* __restrict__ cvt, int T, int t_pad,
                                                              int kmul, half_t* __restrict__ out,
                                                              const int* __restrict__ done, int kv_div) {
-  __shared__ float sm[4][16], sl[4][16];
-  __shared__ float so[4][16][65];
+  __shared__ float sm[CA_WAVES][16], sl[CA_WAVES][16];
+  __shared__ float so[CA_WAVES][16][65];
   const int h = blockIdx.x, c = blockIdx.y;
   if (done && done[c]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int ce = c / kv_div;   // encoder chunk whose K / V^T this decode chunk attends to
-  const half_t* kbase = ck + (size_t)ce * T * d + h * 64;
+  const half_t* kbase = ck + ((size_t)ce * (d >> 6) + h) * T * 64;   // K is head-major: [chunk][head][T][64]
   const half_t* vbase = cvt + ((size_t)ce * d + h * 64) * t_pad;
   half8_t qf[2];
   {
@@ -511,26 +526,36 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const half_t* __res
   float m_run = -1.0e30f, l_run = 0.f;
   const float LOG2E = 1.4426950408889634f;
   const int ngroups = (T + 31) >> 5;
-  for (int gi = wave; gi < ngroups; gi += 4) {
+  // K / V^T fragments of the NEXT key group are requested before the current group is processed
+  // (8 x 16 B per lane always in flight per wave; 8 waves per workgroup): the kernel is a pure HBM stream.
+  auto load_kv = [&](int gi, half8_t (&kf)[4], half8_t (&vf)[4]) {
     const int base = gi * 32;
+    // A rows: key(i, t) = base + 8*(i>>2) + 4*t + (i&3), i = lane&15
+    int k0 = base + 8 * (j >> 2) + (j & 3);
+    int k1 = k0 + 4;
+    if (k0 > T - 1) k0 = T - 1;
+    if (k1 > T - 1) k1 = T - 1;
+    const half_t* p0 = kbase + (size_t)k0 * 64 + g * 8;
+    const half_t* p1 = kbase + (size_t)k1 * 64 + g * 8;
+    kf[0] = *reinterpret_cast<const half8_t*>(p0);
+    kf[1] = *reinterpret_cast<const half8_t*>(p0 + 32);
+    kf[2] = *reinterpret_cast<const half8_t*>(p1);
+    kf[3] = *reinterpret_cast<const half8_t*>(p1 + 32);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      vf[dt] = *reinterpret_cast<const half8_t*>(vbase + (size_t)(dt * 16 + j) * t_pad + base + 8 * g);
+  };
+  half8_t kcur[4], vcur[4], knxt[4], vnxt[4];
+  if (wave < ngroups) load_kv(wave, kcur, vcur);
+  for (int gi = wave; gi < ngroups; gi += CA_WAVES) {
+    const int base = gi * 32;
+    const bool has_next = (gi + CA_WAVES) < ngroups;
+    if (has_next) load_kv(gi + CA_WAVES, knxt, vnxt);
     floatx4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-    {
-      // A rows: key(i, t) = base + 8*(i>>2) + 4*t + (i&3), i = lane&15
-      int k0 = base + 8 * (j >> 2) + (j & 3);
-      int k1 = k0 + 4;
-      if (k0 > T - 1) k0 = T - 1;
-      if (k1 > T - 1) k1 = T - 1;
-      const half_t* p0 = kbase + (size_t)k0 * d + g * 8;
-      const half_t* p1 = kbase + (size_t)k1 * d + g * 8;
-      const half8_t a00 = *reinterpret_cast<const half8_t*>(p0);
-      const half8_t a01 = *reinterpret_cast<const half8_t*>(p0 + 32);
-      const half8_t a10 = *reinterpret_cast<const half8_t*>(p1);
-      const half8_t a11 = *reinterpret_cast<const half8_t*>(p1 + 32);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a00, qf[0], s0, 0, 0, 0);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, qf[1], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, qf[0], s1, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, qf[1], s1, 0, 0, 0);
-    }
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kcur[0], qf[0], s0, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kcur[1], qf[1], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kcur[2], qf[0], s1, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kcur[3], qf[1], s1, 0, 0, 0);
     // lane (query j, g) now holds keys base + 8g + {0..3} (s0) and + {4..7} (s1)
     float sc[8];
     float mx = -1.0e30f;
@@ -559,8 +584,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const half_t* __res
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
-      const half8_t vf = *reinterpret_cast<const half8_t*>(vbase + (size_t)(dt * 16 + j) * t_pad + base + 8 * g);
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vcur[dt], pf, o[dt], 0, 0, 0);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { kcur[q] = knxt[q]; vcur[q] = vnxt[q]; }
     }
   }
   // combine the 4 key-group lanes of a query, then the 4 waves
@@ -572,12 +600,14 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const half_t* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e) so[wave][j][dt * 16 + 4 * g + e] = o[dt][e];
   __syncthreads();
-  for (int idx = tid; idx < kmul * 64; idx += 256) {
+  for (int idx = tid; idx < kmul * 64; idx += CA_WAVES * 64) {
     const int qq = idx >> 6, dh = idx & 63;
-    float M = fmaxf(fmaxf(sm[0][qq], sm[1][qq]), fmaxf(sm[2][qq], sm[3][qq]));
+    float M = sm[0][qq];
+#pragma unroll
+    for (int w = 1; w < CA_WAVES; ++w) M = fmaxf(M, sm[w][qq]);
     float Lsum = 0.f, O = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < CA_WAVES; ++w) {
       const float f = __builtin_amdgcn_exp2f(sm[w][qq] - M);
       Lsum += sl[w][qq] * f;
       O += so[w][qq][dh] * f;
@@ -971,7 +1001,7 @@ __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __re
   float* pr = probs + (((size_t)b * n_sel + hs) * n_tok + tok_idx) * T;
   float mx = -3.0e38f;
   for (int t = tid; t < T; t += 256) {
-    const half8_t* kr = reinterpret_cast<const half8_t*>(ck + ((size_t)b * T + t) * d + h * 64);
+    const half8_t* kr = reinterpret_cast<const half8_t*>(ck + (((size_t)b * (d >> 6) + h) * T + t) * 64);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1054,29 +1084,29 @@ static int gemm_k(hipStream_t st, int mt, int grid, const half_t* x, int ldx, co
 #undef ARGS
 }
 
-template <int MT, int NTW, int KO, int DEPTH, bool LNF>
-static void lds_go(hipStream_t st, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+template <int MT, int NTW, int KO, int DEPTH, bool LNF, bool F32, bool I8>
+static void lds_go(hipStream_t st, int grid, const void* x, int ldx, const void* W, const half_t* bias,
                    const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
-                   int K, int act) {
+                   int K, int act, const float* xs, const float* ws) {
   constexpr int XPAD = (MT * 16 * (KO + 1) + 255) / 256 * 256, WPAD = (NTW * 16 * (KO + 1) + 255) / 256 * 256;
-  static_assert(4 * ((XPAD + WPAD) / 256) <= 63 + 4, "vmcnt range");
   const size_t lds = (size_t)DEPTH * (XPAD + WPAD) * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, F32, I8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int groups = ((R + 15) / 16 + MT - 1) / MT;
-  dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, false><<<dim3(grid, groups), 256, lds, st>>>(x, ldx, W, bias, s1, cf, res,
-                                                                                        ldr, out, ldo, R, N, K, act);
+  dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, F32, I8><<<dim3(grid, groups), 256, lds, st>>>(
+      reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<const half_t*>(W), bias, s1, cf, res, ldr, out, ldo, R,
+      N, K, act, xs, ws);
 }
 
-template <int NTW, int KO, int DEPTH, bool LNF>
-static int lds_mt(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
+template <int NTW, int KO, int DEPTH, bool LNF, bool F32, bool I8>
+static int lds_mt(hipStream_t st, int mt, int grid, const void* x, int ldx, const void* W, const half_t* bias,
                   const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K,
-                  int act) {
-#define GO(MT) lds_go<MT, NTW, KO, DEPTH, LNF>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act)
+                  int act, const float* xs, const float* ws) {
+#define GO(MT) lds_go<MT, NTW, KO, DEPTH, LNF, F32, I8>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws)
   switch (mt) {
     case 1: GO(1); break;
     case 2: GO(2); break;
@@ -1095,20 +1125,58 @@ int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* 
                         int act) {
   if (K % 128 != 0 || R < 1 || R > 80) return -1;
   int mt = (R + 15) / 16;
-  if (N <= 2048 && mt > 2) mt = 2;   // short N: 2 row tiles per workgroup, row groups on grid.y
   const bool lnf = s1 != nullptr;
+  const float* xs = nullptr;
+  const float* ws = nullptr;
+  // tile policy.  "thin" (default): 16/32-column tiles (+ row groups for short N) = many small workgroups,
+  // lowest latency of a single decode stream, and (measured) also the best throughput with 8 batches in
+  // flight (1730 vs 1595).  "fat" (FWAMD_GEMM_TILES=fat): 64-column tiles over all rows = 3x less L2->LDS
+  // re-read of the activations in total, at the price of fewer, longer workgroups.
+  static const int fat = [] { const char* e = getenv("FWAMD_GEMM_TILES"); return (e && e[0] == 'f') ? 1 : 0; }();
+  if (fat && K % 160 == 0 && N >= 64) {
+    const int grid = (N + 63) / 64;
+#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws
+    return lnf ? lds_mt<4, 20, 2, true, false, false>(ARGS) : lds_mt<4, 20, 2, false, false, false>(ARGS);
+#undef ARGS
+  }
+  if (N <= 2048 && mt > 2) mt = 2;   // short N: 2 row tiles per workgroup, row groups on grid.y
   const int ntw = (N <= 4096) ? 1 : 2;
   const int grid = (N + 16 * ntw - 1) / (16 * ntw);
-#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act
+#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws
   // 160-wide slices through a 2-slot ring (<= 82 KB of LDS: two workgroups, e.g. of two worker replicas,
   // fit a CU).  Measured: a 4-slot ring is 11 % faster single-stream (1036 vs 926) but 8 % slower with 8
   // batches in flight (1516 vs 1637), and throughput is what the metric counts.
   if (K % 160 == 0) {
-    if (ntw == 1) return lnf ? lds_mt<1, 20, 2, true>(ARGS) : lds_mt<1, 20, 2, false>(ARGS);
-    return lnf ? lds_mt<2, 20, 2, true>(ARGS) : lds_mt<2, 20, 2, false>(ARGS);
+    if (ntw == 1) return lnf ? lds_mt<1, 20, 2, true, false, false>(ARGS) : lds_mt<1, 20, 2, false, false, false>(ARGS);
+    return lnf ? lds_mt<2, 20, 2, true, false, false>(ARGS) : lds_mt<2, 20, 2, false, false, false>(ARGS);
   }
-  if (ntw == 1) return lnf ? lds_mt<1, 16, 2, true>(ARGS) : lds_mt<1, 16, 2, false>(ARGS);
-  return lnf ? lds_mt<2, 16, 2, true>(ARGS) : lds_mt<2, 16, 2, false>(ARGS);
+  if (ntw == 1) return lnf ? lds_mt<1, 16, 2, true, false, false>(ARGS) : lds_mt<1, 16, 2, false, false, false>(ARGS);
+  return lnf ? lds_mt<2, 16, 2, true, false, false>(ARGS) : lds_mt<2, 16, 2, false, false, false>(ARGS);
+#undef ARGS
+}
+
+// int8 x int8 skinny GEMM (int8_float16 path): xq [R][K] int8 + x_scale[R], Wq [N][K] int8 + w_scale[N].
+// fp16 output (out_f32 = false) or float32 (logits).
+int launch_dec_gemm_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq, const float* w_scale,
+                       const half_t* bias, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
+                       bool out_f32) {
+  if (K % 128 != 0 || R < 1 || R > 80 || !x_scale || !w_scale) return -1;
+  int mt = (R + 15) / 16;
+  if (N <= 2048 && mt > 2) mt = 2;
+  const int ntw = (N <= 4096) ? 1 : 2;
+  const int grid = (N + 16 * ntw - 1) / (16 * ntw);
+  const float* s1 = nullptr;
+  const float* cf = nullptr;
+  const int ldx = K;
+  const void* x = xq;
+  const void* W = Wq;
+#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, x_scale, w_scale
+  if (K % 320 == 0) {   // 16 int8 per 16-byte piece: a 20-piece slice covers 320 elements
+    if (out_f32) return ntw == 1 ? lds_mt<1, 20, 2, false, true, true>(ARGS) : lds_mt<2, 20, 2, false, true, true>(ARGS);
+    return ntw == 1 ? lds_mt<1, 20, 2, false, false, true>(ARGS) : lds_mt<2, 20, 2, false, false, true>(ARGS);
+  }
+  if (out_f32) return ntw == 1 ? lds_mt<1, 8, 2, false, true, true>(ARGS) : lds_mt<2, 8, 2, false, true, true>(ARGS);
+  return ntw == 1 ? lds_mt<1, 8, 2, false, false, true>(ARGS) : lds_mt<2, 8, 2, false, false, true>(ARGS);
 #undef ARGS
 }
 
@@ -1141,7 +1209,7 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div) {
-  dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, t_pad, kmul, out, done, kv_div);
+  dec_cross_attn_kernel<<<dim3(H, B), CA_WAVES * 64, 0, st>>>(qx, d, ck, cvt, T, t_pad, kmul, out, done, kv_div);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {

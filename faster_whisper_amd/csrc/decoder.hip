@@ -28,7 +28,7 @@ using fwd::GenDev;
 
 struct GenWorkspace {
   int B = 0, K = 0, R = 0, NT = 0;
-  half_t *ck = nullptr, *cvt = nullptr;  // [L][B][T][d], [L][B][d][t_pad]
+  half_t *ck = nullptr, *cvt = nullptr;  // K [L][B][H][T][64] (head-major), V^T [L][B][d][t_pad]
   uint64_t ckv_id = 0;                   // id of the encoder output the cross K/V belong to
   half_t *sk = nullptr, *sv = nullptr;   // [L][R][H][NT][64]
   half_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
@@ -127,7 +127,8 @@ static int ensure_cross_kv(Model* m, const Tensor* enc) {
     const DecLayerW& L = m->dec[l];
     half_t* kd = g->ck + (size_t)l * g->B * T * d;
     half_t* vd = g->cvt + (size_t)l * g->B * d * m->t_pad;
-    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, xs, nullptr, 0, 0, T, B, 0, false))) return rc;
+    // K head-major [B][H][T][64]: the decode kernel then streams 192 KB contiguous per (chunk, head)
+    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, xs, nullptr, 0, 0, T, B, 0, false, T))) return rc;
     if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
                          true)))
       return rc;

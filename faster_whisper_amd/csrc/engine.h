@@ -69,7 +69,8 @@ struct LinearW {           // y = x W^T + b ; W [N][K] fp16 (or int8 + per-row s
 struct LNW { const half_t* g = nullptr; const half_t* b = nullptr; };
 
 struct EncLayerW { LNW ln1, ln2; LinearW qk, v, out, ffn1, ffn2; };
-struct DecLayerW { LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };  // qkv, cq, ffn1: LN-folded
+// fp16: qkv, cq, ffn1 are LN-folded (ln1/2/3 unused); int8_float16: explicit LayerNorms feeding the quantiser
+struct DecLayerW { LNW ln1, ln2, ln3; LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };
 
 enum ProfFamily {
   PF_LOGMEL = 0, PF_ENC_GEMM, PF_ENC_ATTN, PF_ENC_LN, PF_CROSS_KV_GEMM,
@@ -112,7 +113,8 @@ struct Model {
   const half_t* tok_emb = nullptr;  // [V][d]
   const half_t* dec_pos = nullptr;  // [n_text_ctx][d]
   std::vector<DecLayerW> dec;
-  LinearW logits;  // final LN folded into the tied-embedding projection
+  LinearW logits;  // final LN folded into the tied-embedding projection (fp16) / int8 tied embedding
+  LNW dec_ln;      // int8_float16 only
 
   // log-mel constants
   float* lm_consts = nullptr;  // cos table [400] + hann [400]
@@ -133,6 +135,8 @@ struct Model {
   half_t* ws_vt = nullptr;                            // [B][d][t_pad]
   half_t* ws_att = nullptr;                           // [B][1500][d]
   half_t* ws_ffn = nullptr;                           // [B][1500][4d]
+  int8_t* ws_xq = nullptr;                            // int8_float16: quantised GEMM input [B*1500][4d]
+  float* ws_xs = nullptr;                             //               its per-row scales [B*1500]
   int t_pad = 0;
 
   GenWorkspace* gen = nullptr;
@@ -163,7 +167,11 @@ inline int dev_alloc_t(T** p, size_t n) { return dev_alloc(reinterpret_cast<void
 
 // linear layer on "many rows": C = act(A W^T + b) + res   (encoder / prefill / align)
 int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t a_bs, half_t* C, int64_t ldc,
-               int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans);
+               int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans,
+               int head_rows = 0);
+
+int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, half_t* C, int64_t ldc, int64_t c_bs,
+                  const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans, int head_rows);
 
 // encoder forward on the channel-last mel image already in m->ws_mel_cl; result into out [B][1500][d]
 int run_encoder(Model* m, int B, half_t* out);

@@ -93,9 +93,14 @@ struct PackItem {
   int64_t dims[4];
   std::vector<uint16_t> data;  // fp16 payload (dtype 1)
   std::vector<float> fdata;    // fp32 payload (dtype 0)
+  std::vector<int8_t> qdata;   // int8 payload (dtype 2)
   int dtype = 1;
-  const void* bytes() const { return dtype == 1 ? (const void*)data.data() : (const void*)fdata.data(); }
-  int64_t nbytes() const { return dtype == 1 ? (int64_t)data.size() * 2 : (int64_t)fdata.size() * 4; }
+  const void* bytes() const {
+    return dtype == 1 ? (const void*)data.data() : dtype == 2 ? (const void*)qdata.data() : (const void*)fdata.data();
+  }
+  int64_t nbytes() const {
+    return dtype == 1 ? (int64_t)data.size() * 2 : dtype == 2 ? (int64_t)qdata.size() : (int64_t)fdata.size() * 4;
+  }
 };
 
 static inline float f16_bits_to_f32(uint16_t u) {
@@ -245,6 +250,47 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     items.push_back(std::move(wf)); items.push_back(std::move(s1)); items.push_back(std::move(cf));
     return FW_OK;
   };
+  // int8_float16 (K25, [CT2-ext] CTranslate2 convention): per output row n, scale = 127 / absmax(W[n,:]),
+  // Wq = rint(W * scale) (round-half-even); the engine stores the DE-quantisation factor absmax / 127.
+  // emits <out>.wq [N][K] int8 and <out>.ws [N] f32
+  auto add_quant = [&](const std::string& out, const std::string& wname, int N, int K) -> int {
+    const fw_weight* W = find_w(w, nw, wname);
+    int rc = expect_shape(W, wname, {N, K});
+    if (rc) return rc;
+    PackItem wq, ws;
+    wq.name = out + ".wq"; wq.ndim = 2; wq.dims[0] = N; wq.dims[1] = K; wq.dims[2] = wq.dims[3] = 1; wq.dtype = 2;
+    ws.name = out + ".ws"; ws.ndim = 1; ws.dims[0] = N; ws.dims[1] = ws.dims[2] = ws.dims[3] = 1; ws.dtype = 0;
+    wq.qdata.resize((size_t)N * K);
+    ws.fdata.resize(N);
+    std::vector<float> row(K);
+    for (int n = 0; n < N; ++n) {
+      float amax = 0.f;
+      for (int k = 0; k < K; ++k) {
+        row[k] = f16_bits_to_f32(f32_to_f16_bits(w_at(W, (int64_t)n * K + k)));
+        amax = std::max(amax, fabsf(row[k]));
+      }
+      const float sc = amax > 0.f ? 127.0f / amax : 0.f;
+      for (int k = 0; k < K; ++k) wq.qdata[(size_t)n * K + k] = (int8_t)lrintf(row[k] * sc);
+      ws.fdata[n] = amax > 0.f ? amax / 127.0f : 1.0f;
+    }
+    items.push_back(std::move(wq)); items.push_back(std::move(ws));
+    return FW_OK;
+  };
+  const bool i8 = compute_type == FW_COMPUTE_INT8_FLOAT16;
+  // a linear layer: fp16 weight (+bias), or int8 weight + scale (+ fp16 bias) in int8_float16 mode
+  auto add_linear = [&](const std::string& base, int N, int K) -> int {
+    int rc = i8 ? add_quant(base, base + ".w", N, K) : add_plain(base + ".w", {N, K});
+    if (rc) return rc;
+    return add_plain(base + ".b", {N});
+  };
+  // a decoder linear fed by a LayerNorm: folded in fp16 mode; explicit LN (quantised output) in int8 mode
+  auto add_ln_linear = [&](const std::string& base, const std::string& ln, int N, int K) -> int {
+    if (!i8) return add_folded(base, base + ".w", base + ".b", ln + ".g", ln + ".b", N, K);
+    int rc = add_linear(base, N, K);
+    if (rc) return rc;
+    if ((rc = add_plain(ln + ".g", {K}))) return rc;
+    return add_plain(ln + ".b", {K});
+  };
   int rc;
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
   TRY(add_conv("enc.conv1", d, nm, c_pad));
@@ -254,11 +300,11 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   for (int i = 0; i < cfg->n_enc_layers; ++i) {
     auto nmf = [&](const char* s) { snprintf(nb, sizeof(nb), "enc.%d.%s", i, s); return std::string(nb); };
     TRY(add_plain(nmf("ln1.g"), {d})); TRY(add_plain(nmf("ln1.b"), {d}));
-    TRY(add_plain(nmf("attn.qkv.w"), {3 * d, d})); TRY(add_plain(nmf("attn.qkv.b"), {3 * d}));
-    TRY(add_plain(nmf("attn.out.w"), {d, d})); TRY(add_plain(nmf("attn.out.b"), {d}));
+    TRY(add_linear(nmf("attn.qkv"), 3 * d, d));
+    TRY(add_linear(nmf("attn.out"), d, d));
     TRY(add_plain(nmf("ln2.g"), {d})); TRY(add_plain(nmf("ln2.b"), {d}));
-    TRY(add_plain(nmf("ffn1.w"), {4 * d, d})); TRY(add_plain(nmf("ffn1.b"), {4 * d}));
-    TRY(add_plain(nmf("ffn2.w"), {d, 4 * d})); TRY(add_plain(nmf("ffn2.b"), {d}));
+    TRY(add_linear(nmf("ffn1"), 4 * d, d));
+    TRY(add_linear(nmf("ffn2"), d, 4 * d));
   }
   TRY(add_plain("enc.ln_post.g", {d})); TRY(add_plain("enc.ln_post.b", {d}));
   TRY(add_plain("dec.tok_emb", {cfg->n_vocab, d}));
@@ -266,15 +312,20 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   for (int i = 0; i < cfg->n_dec_layers; ++i) {
     auto nmf = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
     // the three LayerNorms of a decoder block are folded into the linear that consumes them
-    TRY(add_folded(nmf("self.qkv"), nmf("self.qkv.w"), nmf("self.qkv.b"), nmf("ln1.g"), nmf("ln1.b"), 3 * d, d));
-    TRY(add_plain(nmf("self.out.w"), {d, d})); TRY(add_plain(nmf("self.out.b"), {d}));
-    TRY(add_folded(nmf("cross.q"), nmf("cross.q.w"), nmf("cross.q.b"), nmf("ln2.g"), nmf("ln2.b"), d, d));
-    TRY(add_plain(nmf("cross.kv.w"), {2 * d, d})); TRY(add_plain(nmf("cross.kv.b"), {2 * d}));
-    TRY(add_plain(nmf("cross.out.w"), {d, d})); TRY(add_plain(nmf("cross.out.b"), {d}));
-    TRY(add_folded(nmf("ffn1"), nmf("ffn1.w"), nmf("ffn1.b"), nmf("ln3.g"), nmf("ln3.b"), 4 * d, d));
-    TRY(add_plain(nmf("ffn2.w"), {d, 4 * d})); TRY(add_plain(nmf("ffn2.b"), {d}));
+    TRY(add_ln_linear(nmf("self.qkv"), nmf("ln1"), 3 * d, d));
+    TRY(add_linear(nmf("self.out"), d, d));
+    TRY(add_ln_linear(nmf("cross.q"), nmf("ln2"), d, d));
+    TRY(add_linear(nmf("cross.kv"), 2 * d, d));
+    TRY(add_linear(nmf("cross.out"), d, d));
+    TRY(add_ln_linear(nmf("ffn1"), nmf("ln3"), 4 * d, d));
+    TRY(add_linear(nmf("ffn2"), d, 4 * d));
   }
-  TRY(add_folded("dec.logits", "dec.tok_emb", "", "dec.ln.g", "dec.ln.b", cfg->n_vocab, d));
+  if (i8) {
+    TRY(add_quant("dec.logits", "dec.tok_emb", cfg->n_vocab, d));
+    TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
+  } else {
+    TRY(add_folded("dec.logits", "dec.tok_emb", "", "dec.ln.g", "dec.ln.b", cfg->n_vocab, d));
+  }
 #undef TRY
 
   const int64_t hdr = (int64_t)sizeof(BlobHeader) + (int64_t)items.size() * sizeof(BlobEntry);
@@ -372,6 +423,7 @@ static const half_t* tptr(Model* m, const std::string& name) {
 static int bind_weights(Model* m) {
   const fw_config& c = m->cfg;
   const int d = c.d_model;
+  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   m->c_pad = ((c.n_mels + 63) / 64) * 64;
   auto need = [&](const std::string& n, const half_t** out) -> int {
     *out = tptr(m, n);
@@ -381,63 +433,99 @@ static int bind_weights(Model* m) {
     }
     return FW_OK;
   };
+  auto need_f = [&](const std::string& n, const float** out) -> int {
+    const half_t* p = nullptr;
+    int r = need(n, &p);
+    *out = reinterpret_cast<const float*>(p);
+    return r;
+  };
+  // a linear: fp16 (<base>.w) or int8 (<base>.wq + <base>.ws); bias <base>.b.  rows [r0, r0+N) of the stored matrix
+  auto linear = [&](const std::string& base, LinearW* L, int N, int K, int r0) -> int {
+    int r;
+    *L = LinearW();
+    L->N = N; L->K = K;
+    if (i8) {
+      const half_t* q = nullptr;
+      if ((r = need(base + ".wq", &q))) return r;
+      L->wq = reinterpret_cast<const int8_t*>(q) + (size_t)r0 * K;
+      if ((r = need_f(base + ".ws", &L->wscale))) return r;
+      L->wscale += r0;
+    } else {
+      if ((r = need(base + ".w", &L->w))) return r;
+      L->w += (size_t)r0 * K;
+    }
+    if ((r = need(base + ".b", &L->b))) return r;
+    L->b += r0;
+    return FW_OK;
+  };
+  auto folded = [&](const std::string& base, LinearW* L, int N, int K) -> int {
+    int r;
+    *L = LinearW();
+    if ((r = need(base + ".wf", &L->w))) return r;
+    if ((r = need_f(base + ".s1", &L->s1))) return r;
+    if ((r = need_f(base + ".cf", &L->cf))) return r;
+    L->N = N; L->K = K;
+    return FW_OK;
+  };
+  auto ln = [&](const std::string& base, LNW* L) -> int {
+    int r;
+    if ((r = need(base + ".g", &L->g))) return r;
+    return need(base + ".b", &L->b);
+  };
   int rc;
-#define NEED(n, p) do { if ((rc = need(n, p))) return rc; } while (0)
-  NEED("enc.conv1.wg", &m->conv1.w); NEED("enc.conv1.b", &m->conv1.b);
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+  TRY(need("enc.conv1.wg", &m->conv1.w)); TRY(need("enc.conv1.b", &m->conv1.b));
   m->conv1.N = d; m->conv1.K = 3 * m->c_pad;
-  NEED("enc.conv2.wg", &m->conv2.w); NEED("enc.conv2.b", &m->conv2.b);
+  TRY(need("enc.conv2.wg", &m->conv2.w)); TRY(need("enc.conv2.b", &m->conv2.b));
   m->conv2.N = d; m->conv2.K = 3 * d;
-  NEED("enc.pos", &m->enc_pos);
+  TRY(need("enc.pos", &m->enc_pos));
   m->enc.resize(c.n_enc_layers);
   char nb[96];
   for (int i = 0; i < c.n_enc_layers; ++i) {
     EncLayerW& L = m->enc[i];
     auto nm = [&](const char* s) { snprintf(nb, sizeof(nb), "enc.%d.%s", i, s); return std::string(nb); };
-    const half_t *qkvw, *qkvb;
-    NEED(nm("ln1.g"), &L.ln1.g); NEED(nm("ln1.b"), &L.ln1.b);
-    NEED(nm("attn.qkv.w"), &qkvw); NEED(nm("attn.qkv.b"), &qkvb);
-    L.qk = LinearW{qkvw, qkvb, nullptr, nullptr, nullptr, nullptr, 2 * d, d};
-    L.v = LinearW{qkvw + (size_t)2 * d * d, qkvb + 2 * d, nullptr, nullptr, nullptr, nullptr, d, d};
-    NEED(nm("attn.out.w"), &L.out.w); NEED(nm("attn.out.b"), &L.out.b); L.out.N = d; L.out.K = d;
-    NEED(nm("ln2.g"), &L.ln2.g); NEED(nm("ln2.b"), &L.ln2.b);
-    NEED(nm("ffn1.w"), &L.ffn1.w); NEED(nm("ffn1.b"), &L.ffn1.b); L.ffn1.N = 4 * d; L.ffn1.K = d;
-    NEED(nm("ffn2.w"), &L.ffn2.w); NEED(nm("ffn2.b"), &L.ffn2.b); L.ffn2.N = d; L.ffn2.K = 4 * d;
+    TRY(ln(nm("ln1"), &L.ln1));
+    TRY(linear(nm("attn.qkv"), &L.qk, 2 * d, d, 0));
+    TRY(linear(nm("attn.qkv"), &L.v, d, d, 2 * d));
+    TRY(linear(nm("attn.out"), &L.out, d, d, 0));
+    TRY(ln(nm("ln2"), &L.ln2));
+    TRY(linear(nm("ffn1"), &L.ffn1, 4 * d, d, 0));
+    TRY(linear(nm("ffn2"), &L.ffn2, d, 4 * d, 0));
   }
-  NEED("enc.ln_post.g", &m->enc_ln_post.g); NEED("enc.ln_post.b", &m->enc_ln_post.b);
-  NEED("dec.tok_emb", &m->tok_emb); NEED("dec.pos", &m->dec_pos);
+  TRY(ln("enc.ln_post", &m->enc_ln_post));
+  TRY(need("dec.tok_emb", &m->tok_emb)); TRY(need("dec.pos", &m->dec_pos));
   m->dec.resize(c.n_dec_layers);
-  auto need_f = [&](const std::string& n, const float** out) -> int {
-    *out = reinterpret_cast<const float*>(tptr(m, n));
-    if (!*out) {
-      set_error("weight blob lacks tensor '%s'", n.c_str());
-      return FW_EINVAL;
-    }
-    return FW_OK;
-  };
-  auto folded = [&](const std::string& base, LinearW* L, int N, int K) -> int {
-    int r;
-    if ((r = need(base + ".wf", &L->w))) return r;
-    if ((r = need_f(base + ".s1", &L->s1))) return r;
-    if ((r = need_f(base + ".cf", &L->cf))) return r;
-    L->b = nullptr; L->N = N; L->K = K;
-    return FW_OK;
-  };
   for (int i = 0; i < c.n_dec_layers; ++i) {
     DecLayerW& L = m->dec[i];
     auto nm = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
-    const half_t *kvw, *kvb;
-    if ((rc = folded(nm("self.qkv"), &L.qkv, 3 * d, d))) return rc;
-    NEED(nm("self.out.w"), &L.out.w); NEED(nm("self.out.b"), &L.out.b); L.out.N = d; L.out.K = d;
-    if ((rc = folded(nm("cross.q"), &L.cq, d, d))) return rc;
-    NEED(nm("cross.kv.w"), &kvw); NEED(nm("cross.kv.b"), &kvb);
-    L.ck = LinearW{kvw, kvb, nullptr, nullptr, nullptr, nullptr, d, d};
-    L.cv = LinearW{kvw + (size_t)d * d, kvb + d, nullptr, nullptr, nullptr, nullptr, d, d};
-    NEED(nm("cross.out.w"), &L.cout.w); NEED(nm("cross.out.b"), &L.cout.b); L.cout.N = d; L.cout.K = d;
-    if ((rc = folded(nm("ffn1"), &L.ffn1, 4 * d, d))) return rc;
-    NEED(nm("ffn2.w"), &L.ffn2.w); NEED(nm("ffn2.b"), &L.ffn2.b); L.ffn2.N = d; L.ffn2.K = 4 * d;
+    if (i8) {
+      TRY(ln(nm("ln1"), &L.ln1)); TRY(ln(nm("ln2"), &L.ln2)); TRY(ln(nm("ln3"), &L.ln3));
+      TRY(linear(nm("self.qkv"), &L.qkv, 3 * d, d, 0));
+      TRY(linear(nm("cross.q"), &L.cq, d, d, 0));
+      TRY(linear(nm("ffn1"), &L.ffn1, 4 * d, d, 0));
+    } else {
+      TRY(folded(nm("self.qkv"), &L.qkv, 3 * d, d));
+      TRY(folded(nm("cross.q"), &L.cq, d, d));
+      TRY(folded(nm("ffn1"), &L.ffn1, 4 * d, d));
+    }
+    TRY(linear(nm("self.out"), &L.out, d, d, 0));
+    TRY(linear(nm("cross.kv"), &L.ck, d, d, 0));
+    TRY(linear(nm("cross.kv"), &L.cv, d, d, d));
+    TRY(linear(nm("cross.out"), &L.cout, d, d, 0));
+    TRY(linear(nm("ffn2"), &L.ffn2, d, 4 * d, 0));
   }
-  if ((rc = folded("dec.logits", &m->logits, c.n_vocab, d))) return rc;
-#undef NEED
+  if (i8) {
+    const half_t* q = nullptr;
+    m->logits = LinearW();
+    TRY(need("dec.logits.wq", &q));
+    m->logits.wq = reinterpret_cast<const int8_t*>(q);
+    TRY(need_f("dec.logits.ws", &m->logits.wscale));
+    m->logits.N = c.n_vocab; m->logits.K = d;
+    TRY(ln("dec.ln", &m->dec_ln));
+  } else {
+    TRY(folded("dec.logits", &m->logits, c.n_vocab, d));
+  }
+#undef TRY
   return FW_OK;
 }
 
@@ -462,6 +550,10 @@ static int alloc_workspaces(Model* m) {
   A(m->ws_vt, B * d * m->t_pad);
   A(m->ws_att, B * T * d);
   A(m->ws_ffn, B * T * 4 * d);
+  if (m->compute_type == FW_COMPUTE_INT8_FLOAT16) {
+    A(m->ws_xq, B * T * 4 * d);
+    A(m->ws_xs, B * T);
+  }
 #undef A
   // conv padding rows / V^T time padding must be zero and are never written again
   FW_HIP(hipMemset(m->ws_conv1, 0, B * 3002 * d * sizeof(half_t)));
@@ -530,7 +622,8 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
 
 // ---------------------------------------------------------------- layers
 int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t a_bs, half_t* C, int64_t ldc,
-               int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans) {
+               int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans,
+               int head_rows) {
   fwk::GemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = A; p.lda = lda; p.a_bstride = a_bs;
@@ -540,8 +633,36 @@ int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t
   p.C = C; p.ldc = ldc; p.c_bstride = c_bs;
   p.M = M; p.N = L.N; p.K = L.K;
   p.act = act;
+  p.head_rows = head_rows;
   if (fwk::launch_gemm(m->stream, p, batch, trans) != 0) {
     set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%lld", M, L.N, L.K, (long long)lda);
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
+// int8_float16 linear on "many rows" (K25): per-row dynamic quantisation of A (optionally through the
+// LayerNorm that feeds it), int8 x int8 -> int32 MFMA GEMM, de-quantising epilogue.  A == nullptr reuses the
+// rows quantised by the previous call (fused Q|K and V projections share their input).
+int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, half_t* C, int64_t ldc, int64_t c_bs,
+                  const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans,
+                  int head_rows) {
+  if (A)
+    fwk::launch_quant_rows(m->stream, A, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, m->ws_xq, m->ws_xs, batch * M,
+                           L.K);
+  fwk::GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = reinterpret_cast<const half_t*>(m->ws_xq); p.lda = L.K; p.a_bstride = (int64_t)M * L.K;
+  p.W = reinterpret_cast<const half_t*>(L.wq); p.ldw = L.K;
+  p.bias = L.b;
+  p.res = res; p.ldr = ldr; p.r_bstride = r_bs;
+  p.C = C; p.ldc = ldc; p.c_bstride = c_bs;
+  p.M = M; p.N = L.N; p.K = L.K;
+  p.act = act;
+  p.head_rows = head_rows;
+  p.a_scale = m->ws_xs; p.as_bstride = M; p.w_scale = L.wscale;
+  if (fwk::launch_gemm(m->stream, p, batch, trans) != 0) {
+    set_error("int8 gemm: unsupported shape M=%d N=%d K=%d", M, L.N, L.K);
     return FW_ERUNTIME;
   }
   return FW_OK;
@@ -568,8 +689,35 @@ int run_encoder(Model* m, int B, half_t* out) {
   }
   half_t* x = m->ws_x;
   half_t* x2 = m->ws_x2;
+  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   for (int l = 0; l < c.n_enc_layers; ++l) {
     const EncLayerW& L = m->enc[l];
+    if (i8) {
+      // int8_float16: LayerNorm fused into the quantiser; every linear input is quantised per row
+      {
+        ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * (double)T * d * (3.0 * d), 0);
+        if ((rc = run_linear_i8(m, L.qk, x, &L.ln1, m->ws_qk, 2 * d, (int64_t)T * 2 * d, nullptr, 0, 0, T, B, 0, false,
+                                0)))
+          return rc;
+        if ((rc = run_linear_i8(m, L.v, nullptr, nullptr, m->ws_vt, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T,
+                                B, 0, true, 0)))
+          return rc;
+      }
+      {
+        ProfScope ps(m, PF_ENC_ATTN, 4.0 * B * (double)T * T * d, 0);
+        fwk::launch_attn_enc(m->stream, m->ws_qk, m->ws_qk + d, 2 * d, (int64_t)T * 2 * d, m->ws_vt, m->t_pad,
+                             (int64_t)d * m->t_pad, m->ws_att, d, xs, B, H, T);
+      }
+      {
+        ProfScope ps(m, PF_ENC_GEMM, 2.0 * B * (double)T * d * (9.0 * d), 0);
+        if ((rc = run_linear_i8(m, L.out, m->ws_att, nullptr, x2, d, xs, x, d, xs, T, B, 0, false, 0))) return rc;
+        if ((rc = run_linear_i8(m, L.ffn1, x2, &L.ln2, m->ws_ffn, 4 * d, (int64_t)T * 4 * d, nullptr, 0, 0, T, B, 1,
+                                false, 0)))
+          return rc;
+        if ((rc = run_linear_i8(m, L.ffn2, m->ws_ffn, nullptr, x, d, xs, x2, d, xs, T, B, 0, false, 0))) return rc;
+      }
+      continue;
+    }
     {
       ProfScope ps(m, PF_ENC_LN, 0, 4.0 * B * T * d);
       fwk::launch_layernorm(m->stream, x, L.ln1.g, L.ln1.b, m->ws_xn, B * T, d);
@@ -807,7 +955,7 @@ void fw_model_free(fw_model* fm) {
   m->enc_pool.clear();
   void* ptrs[] = {m->lm_consts, m->lm_filtT, m->ws_pcm, m->ws_offsets, m->ws_raw, m->ws_chunk_max, m->ws_nframes,
                   m->ws_feat32, m->ws_mel_cl, m->ws_conv1, m->ws_x, m->ws_x2, m->ws_xn, m->ws_qk, m->ws_vt,
-                  m->ws_att, m->ws_ffn};
+                  m->ws_att, m->ws_ffn, m->ws_xq, m->ws_xs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (m->blob && m->blob_owned) (void)hipFree(m->blob);
@@ -1101,7 +1249,6 @@ static int download_f16(Model* m, const half_t* src, size_t n, float* dst) {
 int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* bias, const float* residual,
                      int32_t M, int32_t N, int32_t K, int32_t act_gelu, int32_t use_int8, float* out) {
   FW_CHECK_ARG(fm && A && W && out, "null argument");
-  FW_CHECK_ARG(use_int8 == 0, "int8 test path not built yet");
   Model* m = &fm->impl;
   std::lock_guard<std::mutex> lk(m->mu);
   FW_HIP(hipSetDevice(m->device));
@@ -1113,7 +1260,35 @@ int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* 
   if (residual && (rc = upload_f16(m, residual, (size_t)M * N, &dR))) return rc;
   if ((rc = dev_alloc_t(&dC, (size_t)M * N))) return rc;
   LinearW L{dW, dB, nullptr, nullptr, nullptr, nullptr, N, K};
-  if (act_gelu >= 2) {
+  int8_t* dWq = nullptr;
+  float* dWs = nullptr;
+  if (use_int8) {
+    // quantise W per output row exactly like the weight packer, run the int8 path
+    if (m->compute_type != FW_COMPUTE_INT8_FLOAT16 || (int64_t)M * K > (int64_t)m->max_batch * 1500 * 4 * m->cfg.d_model ||
+        M > m->max_batch * 1500) {
+      set_error("int8 gemm test needs an int8_float16 model and M*K within its quantisation workspace");
+      return FW_EINVAL;
+    }
+    std::vector<int8_t> wq((size_t)N * K);
+    std::vector<float> ws(N);
+    for (int n = 0; n < N; ++n) {
+      float amax = 0.f;
+      for (int k = 0; k < K; ++k) amax = std::max(amax, fabsf(f16_bits_to_f32(f32_to_f16_bits(W[(size_t)n * K + k]))));
+      const float sc = amax > 0.f ? 127.0f / amax : 0.f;
+      for (int k = 0; k < K; ++k)
+        wq[(size_t)n * K + k] = (int8_t)lrintf(f16_bits_to_f32(f32_to_f16_bits(W[(size_t)n * K + k])) * sc);
+      ws[n] = amax > 0.f ? amax / 127.0f : 1.0f;
+    }
+    if ((rc = dev_alloc_t(&dWq, wq.size()))) return rc;
+    if ((rc = dev_alloc_t(&dWs, ws.size()))) return rc;
+    FW_HIP(hipMemcpy(dWq, wq.data(), wq.size(), hipMemcpyHostToDevice));
+    FW_HIP(hipMemcpy(dWs, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.wq = dWq; L.wscale = dWs;
+    if (act_gelu >= 2)
+      rc = run_linear_i8(m, L, dA, nullptr, dC, M, 0, nullptr, 0, 0, M, 1, act_gelu - 2, true, 0);
+    else
+      rc = run_linear_i8(m, L, dA, nullptr, dC, N, 0, dR, N, 0, M, 1, act_gelu, false, 0);
+  } else if (act_gelu >= 2) {
     // transposed-output mode: out is [N][M]
     rc = run_linear(m, L, dA, K, 0, dC, M, 0, nullptr, 0, 0, M, 1, act_gelu - 2, true);
   } else {
@@ -1122,6 +1297,8 @@ int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* 
   if (!rc) rc = download_f16(m, dC, (size_t)M * N, out);
   for (half_t* p : {dA, dW, dB, dR, dC})
     if (p) (void)hipFree(p);
+  if (dWq) (void)hipFree(dWq);
+  if (dWs) (void)hipFree(dWs);
   return rc;
 }
 

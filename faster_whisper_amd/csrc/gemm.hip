@@ -34,11 +34,18 @@
 #define GB_K 64
 #define GB_TILE_HALVES (128 * 64)
 
-template <bool TRANS>
+typedef int intx16 __attribute__((ext_vector_type(16)));
+
+// I8: the int8_float16 path (K25): A and W are int8 (per-row dequant scales a_scale[m], w_scale[n]),
+// v_mfma_i32_32x32x32_i8 accumulates in int32, the epilogue de-quantises.  The tile is defined in BYTES
+// (128-byte rows = 64 halves or 128 int8), so staging, swizzle and fragment reads are shared.
+template <bool TRANS, bool I8>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  half_t* sA = reinterpret_cast<half_t*>(smem_raw);     // [2][128][64]
-  half_t* sW = sA + 2 * GB_TILE_HALVES;                 // [2][128][64]
+  constexpr int ES = I8 ? 1 : 2;        // element size
+  constexpr int TILE_BYTES = 128 * 128;
+  char* sA = smem_raw;                  // [2][128 rows][128 B]
+  char* sW = smem_raw + 2 * TILE_BYTES; // [2][128 rows][128 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -52,28 +59,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
   const int mt = bid / p.nNt, nt = bid - mt * p.nNt;
   const int m0 = mt * GB_M, n0 = nt * GB_N;
 
-  const half_t* Ab = p.A + (size_t)z * p.a_bstride;
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)z * p.a_bstride * ES;
+  const char* Wb = reinterpret_cast<const char*>(p.W);
   // staging: direct HBM/L2 -> LDS DMA (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write
   // pass).  A wave instruction fills 64 consecutive 16-byte LDS slots = 8 tile rows; the LDS image must
   // stay lane-linear, so the XOR swizzle is applied to the SOURCE address: LDS slot (row, c') receives
   // global chunk c = c' ^ ((row >> 1) & 7)  (the fragment reads below apply the same involution).
   const int wuni = __builtin_amdgcn_readfirstlane(wave);
-  const half_t* gA[4];
-  const half_t* gW[4];
+  const char* gA[4];
+  const char* gW[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (i * 4 + wuni) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     int am = m0 + row; if (am > p.M - 1) am = p.M - 1;
     int wn_ = n0 + row; if (wn_ > p.N - 1) wn_ = p.N - 1;
-    gA[i] = Ab + (size_t)am * p.lda + c * 8;
-    gW[i] = p.W + (size_t)wn_ * p.ldw + c * 8;
+    gA[i] = Ab + (size_t)am * p.lda * ES + c * 16;
+    gW[i] = Wb + (size_t)wn_ * p.ldw * ES + c * 16;
   }
-  const int nk = p.K / GB_K;
+  const int nk = p.K * ES / 128;
   auto stage = [&](int kt, int buf) {
-    const int koff = kt * GB_K;
-    char* dA = reinterpret_cast<char*>(sA + buf * GB_TILE_HALVES);
-    char* dW = reinterpret_cast<char*>(sW + buf * GB_TILE_HALVES);
+    const int koff = kt * 128;
+    char* dA = sA + buf * TILE_BYTES;
+    char* dW = sW + buf * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + koff),
@@ -86,13 +94,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
   };
   stage(0, 0);
 
-  floatx16 acc[2][2];
+  floatx16 accf[2][2];
+  intx16 acci[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = floatx16{0};
+    for (int j = 0; j < 2; ++j) { accf[i][j] = floatx16{0}; acci[i][j] = intx16{0}; }
 
-  // fragment row bases (in halves) and their swizzle keys
+  // fragment rows and their swizzle keys
   int arow[2], wrow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -108,31 +117,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const half_t* cA = sA + cur * GB_TILE_HALVES;
-    const half_t* cW = sW + cur * GB_TILE_HALVES;
+    const char* cA = sA + cur * TILE_BYTES;
+    const char* cW = sW + cur * TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int chunk = ks * 2 + hi;
-      half8_t fa[2], fw[2];
+      intx4 fa[2], fw[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const half8_t*>(cA + arow[i] * 64 + ((chunk ^ ((arow[i] >> 1) & 7)) << 3));
-        fw[i] = *reinterpret_cast<const half8_t*>(cW + wrow[i] * 64 + ((chunk ^ ((wrow[i] >> 1) & 7)) << 3));
+        fa[i] = *reinterpret_cast<const intx4*>(cA + arow[i] * 128 + ((chunk ^ ((arow[i] >> 1) & 7)) << 4));
+        fw[i] = *reinterpret_cast<const intx4*>(cW + wrow[i] * 128 + ((chunk ^ ((wrow[i] >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (TRANS)  // D[m][n]: acc[mi][ni]
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fw[j], acc[i][j], 0, 0, 0);
-          else        // D[n][m]: acc[ni][mi]
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+          // TRANS: D[m][n] -> acc[mi][ni];  else D[n][m] -> acc[ni][mi]
+          const intx4 opa = TRANS ? fa[i] : fw[i];
+          const intx4 opb = TRANS ? fw[j] : fa[j];
+          if (I8) {
+            acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(opa, opb, acci[i][j], 0, 0, 0);
+          } else {
+            accf[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, opa),
+                                                              __builtin_bit_cast(half8_t, opb), accf[i][j], 0, 0, 0);
+          }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
   // ---------------------------------- epilogue ----------------------------------
+  const float* sa = I8 ? p.a_scale + (size_t)z * p.as_bstride : nullptr;
   if (!TRANS) {
     half_t* Cb = p.C + (size_t)z * p.c_bstride;
     const half_t* Rb = p.res ? p.res + (size_t)z * p.r_bstride : nullptr;
@@ -142,13 +157,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
       for (int mi = 0; mi < 2; ++mi) {
         const int m = m0 + wm * 64 + mi * 32 + l31;
         if (m >= p.M) continue;
+        const float sam = I8 ? sa[m] : 1.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
           if (n >= p.N) continue;
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][g * 4 + e];
+          for (int e = 0; e < 4; ++e)
+            v[e] = I8 ? (float)acci[ni][mi][g * 4 + e] * sam * p.w_scale[n + e] : accf[ni][mi][g * 4 + e];
           if (p.bias) {
             const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + n);
 #pragma unroll
@@ -166,7 +183,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          *reinterpret_cast<half4_t*>(Cb + (size_t)m * p.ldc + n) = o;
+          half_t* dst = p.head_rows > 0 ? Cb + ((size_t)(n >> 6) * p.head_rows + m) * 64 + (n & 63)
+                                        : Cb + (size_t)m * p.ldc + n;
+          *reinterpret_cast<half4_t*>(dst) = o;
         }
       }
   } else {
@@ -178,13 +197,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
         const int n = n0 + wn * 64 + ni * 32 + l31;
         if (n >= p.N) continue;
         const float bv = p.bias ? (float)p.bias[n] : 0.f;
+        const float swn = I8 ? p.w_scale[n] : 1.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int m = m0 + wm * 64 + mi * 32 + 8 * g + 4 * hi;
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = acc[mi][ni][g * 4 + e] + bv;
+            int mm = m + e; if (mm > p.M - 1) mm = p.M - 1;
+            float v = (I8 ? (float)acci[mi][ni][g * 4 + e] * swn * sa[mm] : accf[mi][ni][g * 4 + e]) + bv;
             if (p.act == 1) v = gelu_erf(v);
             o[e] = (half_t)v;
           }
@@ -203,28 +224,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
 
 namespace fwk {
 
-static bool g_gemm_attr_set = false;
-
 int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   GemmParams p = pin;
-  if (p.K % GB_K != 0 || p.K <= 0) return -1;
-  if ((p.lda % 8) || (p.ldw % 8) || (p.a_bstride % 8)) return -1;
+  const bool i8 = p.a_scale != nullptr;
+  const int es = i8 ? 1 : 2;
+  if (p.K <= 0 || (p.K * es) % 128 != 0) return -1;
+  if (((p.lda * es) % 16) || ((p.ldw * es) % 16) || ((p.a_bstride * es) % 16)) return -1;
   if (!trans && ((p.N % 4) || (p.ldc % 4) || (p.c_bstride % 4))) return -1;
+  if (i8 && !p.w_scale) return -1;
   p.nMt = (p.M + GB_M - 1) / GB_M;
   p.nNt = (p.N + GB_N - 1) / GB_N;
-  const int lds = 4 * GB_TILE_HALVES * (int)sizeof(half_t);  // 64 KiB
-  if (!g_gemm_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false>),
+  const int lds = 4 * 128 * 128;  // 64 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    g_gemm_attr_set = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
   }
   const int grid = p.nMt * p.nNt * batch;
-  if (trans)
-    gemm_f16_kernel<true><<<grid, 256, lds, st>>>(p);
-  else
-    gemm_f16_kernel<false><<<grid, 256, lds, st>>>(p);
+  if (i8) {
+    if (trans) gemm_f16_kernel<true, true><<<grid, 256, lds, st>>>(p);
+    else gemm_f16_kernel<false, true><<<grid, 256, lds, st>>>(p);
+  } else {
+    if (trans) gemm_f16_kernel<true, false><<<grid, 256, lds, st>>>(p);
+    else gemm_f16_kernel<false, false><<<grid, 256, lds, st>>>(p);
+  }
   return 0;
 }
 

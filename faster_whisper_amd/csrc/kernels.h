@@ -22,6 +22,9 @@ struct GemmParams {
   half_t* C; int64_t ldc; int64_t c_bstride;          // C[z][m][n]   (TRANS: Ct[z][n][m], ldc = row stride)
   int M, N, K;
   int act;                                            // 0 none, 1 exact GELU
+  int head_rows;                                      // > 0: head-major output C[z][n/64][m][n%64] with head_rows rows per head
+  // int8 path (a_scale != null): A and W point to int8 data; dequant scales per A row / per W row
+  const float* a_scale; int64_t as_bstride; const float* w_scale;
   int nMt, nNt;                                       // filled by launch_gemm
 };
 int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
@@ -29,6 +32,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
 // ---- row kernels (rowops.hip) -----------------------------------------------------
 // y[r] = LN(x[r]) * g + b, eps 1e-5, fp32 statistics (two-pass in registers)
 void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d);
+// per-row dynamic int8 quantisation (absmax / 127), optionally preceded by LayerNorm (g != null):
+// xq[r][:] = rint(y * 127 / absmax(y)), scale[r] = absmax / 127 with y = LN(x[r]) rounded to fp16, or x[r]
+void launch_quant_rows(hipStream_t st, const half_t* x, int64_t ldx, const half_t* g, const half_t* b, int8_t* xq,
+                       float* scale, int rows, int d);
 void launch_f32_to_f16(hipStream_t st, const float* x, half_t* y, int64_t n);
 void launch_f16_to_f32(hipStream_t st, const half_t* x, float* y, int64_t n);
 
