@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=100)
     ap.add_argument("--workers", type=int, default=8,
                     help="batches kept in flight per GPU (worker replicas sharing the weights)")
+    ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
+                    help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
@@ -75,16 +77,16 @@ def main():
         blob = None
         if rank == 0:
             weights = synthetic_weights(cfg, seed=1234)
-            blob = pack_blob(cfg, weights)
+            blob = pack_blob(cfg, weights, 1 if args.compute_type == "int8_float16" else 0)
         dev_blob = broadcast_blob(blob, rank, local_rank)           # RCCL broadcast over xGMI
         model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
                         max_batch_size=args.batch, max_beam_size=args.beam, inter_threads=args.workers,
-                        blob_dev=(dev_blob.data_ptr(), dev_blob.numel()))
+                        compute_type=args.compute_type, blob_dev=(dev_blob.data_ptr(), dev_blob.numel()))
     else:
         weights = synthetic_weights(cfg, seed=1234)
         model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
                         files={"config": cfg, "weights": weights}, max_batch_size=args.batch,
-                        max_beam_size=args.beam, inter_threads=args.workers)
+                        max_beam_size=args.beam, inter_threads=args.workers, compute_type=args.compute_type)
     load_s = time.time() - t0
 
     chunks = synth_chunks(args.batch, seed=1000 + rank)
@@ -151,8 +153,8 @@ def main():
         "metric": "audio-sec/sec (RTF) large-v3 fp16 beam=5 batch=16", "value": round(value, 2),
         "unit": "audio-seconds per wall-second", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / max(1, args.steps), 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{args.model} fp16 BatchedInferencePipeline hot path: {args.batch} x 30 s chunks/step, "
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.compute_type == "float16" else "i8/f16", "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.compute_type} BatchedInferencePipeline hot path: {args.batch} x 30 s chunks/step, "
                                f"beam_size={args.beam}, {L} new tokens/chunk (fixed), PCM resident in HBM",
                    "global_batch": args.batch * world, "new_tokens": L, "batches_in_flight_per_gpu": W, "model_load_s": round(load_s, 1)},
     }

@@ -46,6 +46,8 @@ struct GenWorkspace {
   float* no_speech = nullptr;
   uint8_t* sup_mask = nullptr;
   int* zero_done = nullptr;              // [B] zeros (kernels that take a `done` pointer outside generate)
+  int8_t* xq = nullptr;                  // int8_float16: quantised linear input [R][4d]
+  float* xs = nullptr;                   //               per-row de-quantisation scale [R]
   // graph cache for the decode step
   hipGraphExec_t graph = nullptr;
   GenDev graph_key;
@@ -91,6 +93,10 @@ int gen_workspace_create(Model* m) {
   A(g->no_speech, Rg);
   A(g->sup_mask, (size_t)c.n_vocab);
   A(g->zero_done, Rg);
+  if (m->compute_type == FW_COMPUTE_INT8_FLOAT16) {
+    A(g->xq, Rg * 4 * d);
+    A(g->xs, Rg);
+  }
 #undef A
   FW_HIP(hipMemset(g->cvt, 0, L * B * d * m->t_pad * sizeof(half_t)));
   FW_HIP(hipMemset(g->zero_done, 0, Rg * sizeof(int)));
@@ -107,7 +113,7 @@ void gen_workspace_free(Model* m) {
   void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->xn, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_mask,
-                  g->zero_done};
+                  g->zero_done, g->xq, g->xs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -123,10 +129,21 @@ static int ensure_cross_kv(Model* m, const Tensor* enc) {
   const int64_t xs = (int64_t)T * d;
   int rc;
   ProfScope ps(m, PF_CROSS_KV_GEMM, 2.0 * c.n_dec_layers * B * (double)T * d * (2.0 * d), 0);
+  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
     half_t* kd = g->ck + (size_t)l * g->B * T * d;
     half_t* vd = g->cvt + (size_t)l * g->B * d * m->t_pad;
+    if (i8) {
+      // the encoder output is quantised once (layer 0) and shared by all 2L projections
+      if ((rc = run_linear_i8(m, L.ck, l == 0 ? enc->data : nullptr, nullptr, kd, d, xs, nullptr, 0, 0, T, B, 0, false,
+                              T)))
+        return rc;
+      if ((rc = run_linear_i8(m, L.cv, nullptr, nullptr, vd, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
+                              true, 0)))
+        return rc;
+      continue;
+    }
     // K head-major [B][H][T][64]: the decode kernel then streams 192 KB contiguous per (chunk, head)
     if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, xs, nullptr, 0, 0, T, B, 0, false, T))) return rc;
     if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
@@ -176,7 +193,16 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   }
   // one decoder linear: x[rows][K] -> out[rows][N]; LayerNorm-folded when L.s1 is set; in-place residual
   static const bool use_lds_gemm = !(getenv("FWAMD_REG_GEMM") && getenv("FWAMD_REG_GEMM")[0] == '1');
-  auto lin = [&](const half_t* xin, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
+  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
+  // int8_float16 (K25): the row quantiser (fused with the LayerNorm where one feeds the linear) runs as its
+  // own tiny kernel, then the int8 skinny GEMM de-quantises in its epilogue
+  auto lin_q = [&](const half_t* xin, const LNW* ln, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
+    fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K);
+    return fwd::launch_dec_gemm_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K, act,
+                                   false);
+  };
+  auto lin = [&](const half_t* xin, const LNW* ln, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
+    if (i8) return lin_q(xin, ln, L, res, outp, act);
     if (use_lds_gemm)
       return fwd::launch_dec_gemm_lds(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act);
     return fwd::launch_dec_gemm(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act, false);
@@ -189,7 +215,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * m->t_pad;
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
-      DG(lin(g->x, L.qkv, nullptr, g->qkv, 0));
+      DG(lin(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
     }
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0);
@@ -198,8 +224,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
-      DG(lin(g->att, L.out, g->x, g->x, 0));
-      DG(lin(g->x, L.cq, nullptr, g->qc, 0));
+      DG(lin(g->att, nullptr, L.out, g->x, g->x, 0));
+      DG(lin(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0);
@@ -213,21 +239,27 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d);
-      DG(lin(g->att, L.cout, g->x, g->x, 0));
+      DG(lin(g->att, nullptr, L.cout, g->x, g->x, 0));
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      DG(lin(g->x, L.ffn1, nullptr, g->ffn, 1));
+      DG(lin(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      DG(lin(g->ffn, L.ffn2, g->x, g->x, 0));
+      DG(lin(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
     }
   }
   if (s.need_logits || s.beam_tail) {
     ProfScope ps(m, PF_DEC_LOGITS, 2.0 * rows * (double)c.n_vocab * d, 2.0 * c.n_vocab * d);
-    DG(fwd::launch_dec_gemm(st, g->x, d, m->logits.w, nullptr, m->logits.s1, m->logits.cf, nullptr, 0, g->logits,
-                            c.n_vocab, rows, c.n_vocab, d, 0, true));
+    if (i8) {
+      fwk::launch_quant_rows(st, g->x, d, m->dec_ln.g, m->dec_ln.b, g->xq, g->xs, rows, d);
+      DG(fwd::launch_dec_gemm_i8(st, g->xq, g->xs, m->logits.wq, m->logits.wscale, nullptr, nullptr, 0, g->logits,
+                                 c.n_vocab, rows, c.n_vocab, d, 0, true));
+    } else {
+      DG(fwd::launch_dec_gemm(st, g->x, d, m->logits.w, nullptr, m->logits.s1, m->logits.cf, nullptr, 0, g->logits,
+                              c.n_vocab, rows, c.n_vocab, d, 0, true));
+    }
   }
   if (s.nospeech_rowmul > 0) {
     ProfScope ps(m, PF_DEC_MISC, 0, 0);

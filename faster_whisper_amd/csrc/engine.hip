@@ -308,6 +308,18 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   }
   TRY(add_plain("enc.ln_post.g", {d})); TRY(add_plain("enc.ln_post.b", {d}));
   TRY(add_plain("dec.tok_emb", {cfg->n_vocab, d}));
+  if (i8) {
+    // [CT2-ext] the token embedding shares the int8 projection weight: a lookup returns the de-quantised row
+    PackItem& te = items.back();
+    const int64_t K = d;
+    for (int64_t n = 0; n < cfg->n_vocab; ++n) {
+      float amax = 0.f;
+      for (int64_t k = 0; k < K; ++k) amax = std::max(amax, fabsf(f16_bits_to_f32(te.data[n * K + k])));
+      const float sc = amax > 0.f ? 127.0f / amax : 0.f, ds = amax > 0.f ? amax / 127.0f : 1.0f;
+      for (int64_t k = 0; k < K; ++k)
+        te.data[n * K + k] = f32_to_f16_bits((float)lrintf(f16_bits_to_f32(te.data[n * K + k]) * sc) * ds);
+    }
+  }
   TRY(add_plain("dec.pos", {cfg->n_text_ctx, d}));
   for (int i = 0; i < cfg->n_dec_layers; ++i) {
     auto nmf = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };

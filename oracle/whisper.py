@@ -19,6 +19,13 @@ Numerics: float32 torch on the CPU.  With `emulate_fp16=True` the tensors the GP
 stores in fp16 (weights, activations between kernels, attention probabilities) are rounded
 to fp16 at the same points, so the remaining engine-vs-oracle difference is accumulation
 order only.
+
+`int8=True` restates compute_type "int8_float16" ([CT2-ext] CTranslate2 convention): every Dense
+weight is quantised per output row (scale = 127 / absmax, round-half-even), every Dense input is
+quantised per row the same way at run time, the product is accumulated exactly in integers and
+de-quantised by (row scale x weight scale); convolutions, LayerNorm, attention and the residual
+stream stay fp16.  The token embedding shares the quantised projection weight, so a lookup
+returns the de-quantised row.
 """
 import math
 from dataclasses import dataclass, field
@@ -57,14 +64,48 @@ def max_new_tokens(max_length: int, prompt_len: int) -> int:
 
 
 class OracleWhisper:
-    def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_fp16: bool = False, threads: Optional[int] = None):
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_fp16: bool = False, threads: Optional[int] = None,
+                 int8: bool = False):
         if threads:
             torch.set_num_threads(threads)
         self.cfg = cfg
-        self.h = emulate_fp16
+        self.h = emulate_fp16 or int8
+        self.int8 = int8
         self.w = {k: self._r(_t(v)) for k, v in weights.items()}
         d = cfg.d_model
         self.d, self.H = d, cfg.n_heads
+        self.q = {}
+        if int8:
+            for k, v in self.w.items():
+                if k.endswith(".w") and v.dim() == 2:
+                    self.q[k] = self._quant_rows(v)
+            wq, ws = self._quant_rows(self.w["dec.tok_emb"])
+            self.q["dec.tok_emb"] = (wq, ws)
+            self.w["dec.tok_emb"] = self._r(wq.float() * ws[:, None])
+
+    @staticmethod
+    def _quant_rows(x: torch.Tensor):
+        """per-row symmetric int8: q = rint(x * (127 / absmax)), de-quantisation factor absmax / 127
+        (float32 arithmetic, round-half-even; an all-zero row gets q = 0, factor 1)"""
+        amax = x.abs().amax(dim=-1)
+        one = torch.tensor(127.0, dtype=torch.float32)
+        inv = torch.where(amax > 0, one / amax, torch.zeros_like(amax))
+        ds = torch.where(amax > 0, amax / one, torch.ones_like(amax))
+        q = torch.round(x * inv.unsqueeze(-1)).to(torch.int32)
+        return q, ds
+
+    def _qmatmul(self, x: torch.Tensor, key: str) -> torch.Tensor:
+        """int8_float16 Dense core: quantise the rows of x, exact integer product, de-quantise"""
+        wq, ws = self.q[key]
+        xq, xs = self._quant_rows(x)
+        acc = torch.matmul(xq.double(), wq.double().t())        # exact: |acc| < 2^53
+        return acc.float() * xs.unsqueeze(-1) * ws
+
+    def _dense(self, x: torch.Tensor, key: str, bias_key: Optional[str]) -> torch.Tensor:
+        if self.int8:
+            y = self._qmatmul(x, key)
+            return y + self.w[bias_key] if bias_key else y
+        return torch.nn.functional.linear(x, self.w[key], self.w[bias_key] if bias_key else None)
 
     # fp16 rounding point
     def _r(self, x: torch.Tensor) -> torch.Tensor:
@@ -74,7 +115,7 @@ class OracleWhisper:
         return self._r(torch.nn.functional.layer_norm(x, (self.d,), self.w[p + ".g"], self.w[p + ".b"], 1e-5))
 
     def _lin(self, x, p, act=False, res=None):
-        y = torch.nn.functional.linear(x, self.w[p + ".w"], self.w[p + ".b"])
+        y = self._dense(x, p + ".w", p + ".b")
         if act:
             y = torch.nn.functional.gelu(y)  # exact erf GELU
         if res is not None:
@@ -125,7 +166,7 @@ class OracleWhisper:
         out = []
         for i in range(self.cfg.n_dec_layers):
             p = f"dec.{i}.cross.kv"
-            kv = self._r(torch.nn.functional.linear(enc, self.w[p + ".w"], self.w[p + ".b"]))
+            kv = self._r(self._dense(enc, p + ".w", p + ".b"))
             k, v = kv.split(self.d, dim=-1)
             out.append((self._heads(k), self._heads(v)))
         return out
@@ -158,7 +199,7 @@ class OracleWhisper:
         return (x, probs) if return_cross_probs else x
 
     def logits(self, hidden: torch.Tensor) -> torch.Tensor:
-        return torch.nn.functional.linear(hidden, self.w["dec.tok_emb"])
+        return self._dense(hidden, "dec.tok_emb", None)
 
     class _Cache:
         """self-attention K/V per layer for R rows, positions filled so far"""

@@ -1,0 +1,174 @@
+"""compute_type="int8_float16" (kernel K25): the int8 MFMA GEMMs, the row
+quantiser and the end-to-end engine against the oracle's int8 restatement (oracle/whisper.py, int8=True).
+
+Integer accumulation is exact on both sides, so a single linear agrees to fp16 output rounding.  End to end
+the only noise source is a LayerNorm / attention value that lands 1 fp16 ulp apart and flips one int8 code;
+tolerances are those of the fp16 tests, loosened where a flipped code is visible."""
+import numpy as np
+import pytest
+
+from conftest import bench_audio, make_model
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 4e-2
+
+
+def _h(x):
+    return x.astype(np.float16).astype(np.float32)
+
+
+def _quant_rows(x):
+    amax = np.abs(x).max(axis=-1).astype(np.float32)
+    inv = np.where(amax > 0, np.float32(127.0) / np.where(amax > 0, amax, 1), 0).astype(np.float32)
+    ds = np.where(amax > 0, amax / np.float32(127.0), 1).astype(np.float32)
+    q = np.rint(x.astype(np.float32) * inv[..., None]).astype(np.int64)
+    return q, ds
+
+
+@pytest.fixture(scope="module")
+def kmodel():
+    cfg, w, m = make_model("micro", max_batch=2, max_beam=2, compute_type="int8_float16")
+    return m
+
+
+def _gemm_i8(model, A, W, bias=None, res=None, act=0):
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((N, M) if act >= 2 else (M, N), dtype=np.float32)
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    bp = _lib.ptr(np.ascontiguousarray(bias, np.float32)) if bias is not None else None
+    rp = _lib.ptr(np.ascontiguousarray(res, np.float32)) if res is not None else None
+    _lib.check(lib.fw_test_gemm(model._replicas[0].handle, _lib.ptr(A), _lib.ptr(W), bp, rp, M, N, K, act, 1,
+                                _lib.ptr(out)))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 384), (300, 256, 128), (1500, 512, 512),
+                                   (77, 128, 256), (1500, 128, 512)])
+def test_gemm_int8_exact(kmodel, M, N, K):
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = _h(rng.standard_normal((M, K)).astype(np.float32))
+    A[min(5, M - 1)] = 0.0                       # an all-zero row: scale 1, codes 0
+    W = _h((rng.standard_normal((N, K)) * (0.2 + np.arange(N)[:, None] / N)).astype(np.float32))
+    b = _h(rng.standard_normal(N).astype(np.float32))
+    out = _gemm_i8(kmodel, A, W, bias=b)
+    aq, a_s = _quant_rows(A)
+    wq, w_s = _quant_rows(W)
+    acc = (aq @ wq.T).astype(np.float32)
+    ref = _h(acc * a_s[:, None] * w_s[None, :] + b)
+    err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+    print(f"int8 gemm {M}x{N}x{K}: rel err vs integer reference {err:.2e}")
+    assert err < 1e-3                             # fp16 output rounding only
+    # and the quantised product is a sane approximation of the fp32 one
+    full = A @ W.T + b
+    assert np.abs(out - full).max() / np.abs(full).max() < 5e-2
+
+
+def test_gemm_int8_transposed_epilogue(kmodel):
+    rng = np.random.default_rng(9)
+    M, N, K = 200, 128, 256
+    A = _h(rng.standard_normal((M, K)).astype(np.float32))
+    W = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.3)
+    b = _h(rng.standard_normal(N).astype(np.float32))
+    out = _gemm_i8(kmodel, A, W, bias=b, act=2)   # act 2 = transposed store, no activation
+    aq, a_s = _quant_rows(A)
+    wq, w_s = _quant_rows(W)
+    ref = _h((aq @ wq.T).astype(np.float32) * a_s[:, None] * w_s[None, :] + b).T
+    assert out.shape == (N, M)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-3
+
+
+@pytest.fixture(scope="module", params=["micro", "tiny.en"])
+def setup(request):
+    from oracle.whisper import OracleWhisper
+    cfg, w, model = make_model(request.param, seed=11, max_batch=4, max_beam=5, compute_type="int8_float16")
+    oracle = OracleWhisper(cfg, w, int8=True)
+    chunks = [bench_audio(480000, seed=1), bench_audio(200000, seed=2), bench_audio(480000, seed=3)[::-1].copy()]
+    feats = model.log_mel(chunks)
+    return cfg, model, oracle, feats
+
+
+def _prompt(cfg, timestamps=False):
+    p = list(cfg.sot_sequence)
+    if not timestamps:
+        p.append(cfg.no_timestamps)
+    return p
+
+
+def _suppress(cfg):
+    return sorted({cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe, 1, 2, 7})
+
+
+def test_compute_type_reported(setup):
+    cfg, model, oracle, feats = setup
+    assert model.compute_type == "int8_float16"
+
+
+def test_encode_int8(setup):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    got = model.encode(StorageView.from_array(feats)).to_numpy()
+    ref = oracle.encode(feats)
+    err = float(np.abs(got - ref).max())
+    rel = err / float(np.abs(ref).max())
+    rms = float(np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+    print(f"[{cfg.name}] int8 encoder: max abs err {err:.3e} (rel {rel:.2e}), rms rel {rms:.2e}")
+    assert rel < 3e-2 and rms < 1.5e-2   # a flipped int8 code is ~1/127 of a row's absmax
+
+
+def test_generate_int8_teacher_forced(setup):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    prompt = _prompt(cfg)
+    kw = dict(beam_size=1, max_length=len(prompt) + 16, suppress_tokens=_suppress(cfg), length_penalty=0.0)
+    got = model.generate(enc, [prompt] * 3, return_scores=True, **kw)
+    ref = oracle.generate(enc_np, [prompt] * 3, force_tokens=[g.sequences_ids[0] for g in got], **kw)
+    for g, r in zip(got, ref):
+        assert r.sequences_ids[0] == g.sequences_ids[0]
+        print(f"[{cfg.name}] int8 teacher-forced cum logprob {g.scores[0]:.5f} vs {r.scores[0]:.5f}")
+        assert abs(g.scores[0] - r.scores[0]) < 5e-3 * max(1.0, abs(r.scores[0]))
+
+
+@pytest.mark.parametrize("beam", [1, 5])
+def test_generate_int8(setup, beam):
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    enc = model.encode(StorageView.from_array(feats))
+    enc_np = enc.to_numpy()
+    prompt = _prompt(cfg, timestamps=True)
+    kw = dict(beam_size=beam, max_length=len(prompt) + 16, suppress_blank=True, suppress_tokens=_suppress(cfg),
+              max_initial_timestamp_index=50)
+    got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+    ref = oracle.generate(enc_np, [prompt] * 3, **kw)
+    same = 0
+    for b, (g, r) in enumerate(zip(got, ref)):
+        eq = g.sequences_ids[0] == r.sequences_ids[0]
+        same += eq
+        print(f"[{cfg.name}] int8 beam={beam} chunk {b}: equal={eq} score {g.scores[0]:.5f} vs {r.scores[0]:.5f}")
+        if beam == 1:
+            n = 0
+            while n < len(r.margins) and n < len(r.sequences_ids[0]) and r.margins[n] > MARGIN:
+                n += 1
+            assert g.sequences_ids[0][:n] == r.sequences_ids[0][:n]
+        if eq:
+            assert abs(g.scores[0] - r.scores[0]) < 5e-3 * max(1.0, abs(r.scores[0]))
+        assert abs(g.no_speech_prob - r.no_speech_prob) < 2e-3
+    assert same >= 1   # low-margin flips are more frequent than in fp16; the margin-safe prefix above is the gate
+
+
+def test_int8_tracks_float16(setup):
+    """the quantised engine stays close to the fp16 engine on the same weights (sanity of the whole int8 flow)"""
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    _, _, ref_model = make_model(cfg.name, seed=11, max_batch=4, max_beam=5)
+    a = model.encode(StorageView.from_array(feats)).to_numpy()
+    b = ref_model.encode(StorageView.from_array(feats)).to_numpy()
+    rms = float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    print(f"[{cfg.name}] int8 vs fp16 encoder output: rms rel {rms:.3e}")
+    assert rms < 0.1
