@@ -36,7 +36,7 @@ int launch_dec_gemm_i8(hipStream_t st, const int8_t* xq, const float* x_scale, c
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total);
-void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
+void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div);
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
 void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
@@ -47,7 +47,7 @@ void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val,
 void launch_step_advance(hipStream_t st, int* d_step);
 void launch_token_prob(hipStream_t st, const float* logits, int V, const int* target, float* out, int out_stride,
                        int out_off, int rows);
-void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, const int* heads,
+void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, int kvp, const int* heads,
                         int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B);
 
 }  // namespace fwd

@@ -486,13 +486,17 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
 // every byte is used exactly once per workgroup).
 //   S^T tile = K rows x Q^T     (A row i of sub-tile t holds key base+8*(i>>2)+4t+(i&3), so a
 //                                lane ends with 8 CONSECUTIVE keys of its query)
-//   O^T tile = V^T x P^T        (A = 16 bytes of a time-contiguous V^T row)
-// 4 waves stride over 32-key groups with an online softmax each; merged through LDS.
+//   O^T tile = V^T x P^T        (A = 8 consecutive keys of one V^T row)
+// K and V^T are stored FRAGMENT-MAJOR by the projection GEMM's epilogue (gemm.hip): the 16 bytes
+// lane l needs for operand run q of key group gi sit at ((gi*4 + q)*64 + l)*16 B, so every load
+// instruction of a wave is one contiguous 1 KB run and a (chunk, head) is two linear 192 KB streams
+// (row-shaped fragment loads of 64 B out of 16 different lines were texture-address bound).
+// The waves stride over 32-key groups with an online softmax each; merged through LDS.
 // ------------------------------------------------------------------------------------
-#define CA_WAVES 8
+template <int CA_WAVES>
 __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
                                                              const half_t* __restrict__ ck,
-                                                             const half_t* __restrict__ cvt, int T, int t_pad,
+                                                             const half_t* __restrict__ cvt, int T, int kvp,
                                                              int kmul, half_t* __restrict__ out,
                                                              const int* __restrict__ done, int kv_div) {
   __shared__ float sm[CA_WAVES][16], sl[CA_WAVES][16];
@@ -502,8 +506,8 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int ce = c / kv_div;   // encoder chunk whose K / V^T this decode chunk attends to
-  const half_t* kbase = ck + ((size_t)ce * (d >> 6) + h) * T * 64;   // K is head-major: [chunk][head][T][64]
-  const half_t* vbase = cvt + ((size_t)ce * d + h * 64) * t_pad;
+  const half_t* kbase = ck + ((size_t)ce * (d >> 6) + h) * kvp * 64 + lane * 8;   // [chunk][head][group][run][lane][8]
+  const half_t* vbase = cvt + ((size_t)ce * (d >> 6) + h) * kvp * 64 + lane * 8;
   half8_t qf[2];
   {
     if (j < kmul) {
@@ -529,21 +533,13 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
   // K / V^T fragments of the NEXT key group are requested before the current group is processed
   // (8 x 16 B per lane always in flight per wave; 8 waves per workgroup): the kernel is a pure HBM stream.
   auto load_kv = [&](int gi, half8_t (&kf)[4], half8_t (&vf)[4]) {
-    const int base = gi * 32;
-    // A rows: key(i, t) = base + 8*(i>>2) + 4*t + (i&3), i = lane&15
-    int k0 = base + 8 * (j >> 2) + (j & 3);
-    int k1 = k0 + 4;
-    if (k0 > T - 1) k0 = T - 1;
-    if (k1 > T - 1) k1 = T - 1;
-    const half_t* p0 = kbase + (size_t)k0 * 64 + g * 8;
-    const half_t* p1 = kbase + (size_t)k1 * 64 + g * 8;
-    kf[0] = *reinterpret_cast<const half8_t*>(p0);
-    kf[1] = *reinterpret_cast<const half8_t*>(p0 + 32);
-    kf[2] = *reinterpret_cast<const half8_t*>(p1);
-    kf[3] = *reinterpret_cast<const half8_t*>(p1 + 32);
+    const half_t* kp = kbase + (size_t)gi * 2048;
+    const half_t* vp = vbase + (size_t)gi * 2048;
+    // K runs: q = 2*sub + s (sub: keys +0 / +4 of the interleaved A rows, s: dims 0-31 / 32-63)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      vf[dt] = *reinterpret_cast<const half8_t*>(vbase + (size_t)(dt * 16 + j) * t_pad + base + 8 * g);
+    for (int q = 0; q < 4; ++q) kf[q] = *reinterpret_cast<const half8_t*>(kp + q * 512);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = *reinterpret_cast<const half8_t*>(vp + dt * 512);
   };
   half8_t kcur[4], vcur[4], knxt[4], vnxt[4];
   if (wave < ngroups) load_kv(wave, kcur, vcur);
@@ -988,7 +984,7 @@ __global__ __launch_bounds__(1024) void dec_token_prob_kernel(const float* __res
 // cross-attention probabilities of selected heads for align:
 // probs[b][hsel][tok][t] = softmax_t( q[b][head] . K[b][t][head] / 8 ),  one workgroup per (hsel, b)
 __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __restrict__ qx, int d,
-                                                              const half_t* __restrict__ ck, int T,
+                                                              const half_t* __restrict__ ck, int T, int kvp,
                                                               const int* __restrict__ heads, int n_sel,
                                                               float* __restrict__ probs, int n_tok, int tok_idx) {
   __shared__ float sq[64];
@@ -1001,11 +997,14 @@ __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __re
   float* pr = probs + (((size_t)b * n_sel + hs) * n_tok + tok_idx) * T;
   float mx = -3.0e38f;
   for (int t = tid; t < T; t += 256) {
-    const half8_t* kr = reinterpret_cast<const half8_t*>(ck + (((size_t)b * (d >> 6) + h) * T + t) * 64);
+    // fragment-major K (see K14): dims 8j..8j+7 of key t live in run 2*sub + (j>>2), lane 16*(j&3) + jj
+    const int r = t & 31;
+    const half_t* kb = ck + ((size_t)b * (d >> 6) + h) * kvp * 64 +
+                       ((size_t)((t >> 5) * 4 + 2 * ((r >> 2) & 1)) * 64 + (((r >> 3) << 2) | (r & 3))) * 8;
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const half8_t kv = kr[j];
+      const half8_t kv = *reinterpret_cast<const half8_t*>(kb + ((size_t)(j >> 2) * 64 + (j & 3) * 16) * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += sq[j * 8 + e] * (float)kv[e];
     }
@@ -1140,13 +1139,25 @@ int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* 
 #undef ARGS
   }
   if (N <= 2048 && mt > 2) mt = 2;   // short N: 2 row tiles per workgroup, row groups on grid.y
-  const int ntw = (N <= 4096) ? 1 : 2;
+  // experiment knobs (profiles/README.md): FWAMD_GEMM_MT caps the row tiles per workgroup for every N
+  // (more, smaller workgroups per CU), FWAMD_GEMM_DEPTH=4 deepens the ring where it still fits in LDS
+  static const int env_mt = [] { const char* e = getenv("FWAMD_GEMM_MT"); return e ? atoi(e) : 0; }();
+  static const int env_depth = [] { const char* e = getenv("FWAMD_GEMM_DEPTH"); return e ? atoi(e) : 2; }();
+  static const int env_ntw = [] { const char* e = getenv("FWAMD_GEMM_NTW"); return e ? atoi(e) : 0; }();
+  if (env_mt >= 1 && env_mt <= 5 && mt > env_mt) mt = env_mt;
+  int ntw = (N <= 4096) ? 1 : 2;
+  if (env_ntw == 1 || env_ntw == 2) ntw = env_ntw;
   const int grid = (N + 16 * ntw - 1) / (16 * ntw);
 #define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws
   // 160-wide slices through a 2-slot ring (<= 82 KB of LDS: two workgroups, e.g. of two worker replicas,
   // fit a CU).  Measured: a 4-slot ring is 11 % faster single-stream (1036 vs 926) but 8 % slower with 8
   // batches in flight (1516 vs 1637), and throughput is what the metric counts.
   if (K % 160 == 0) {
+    const int slot = (((mt * 16 * 21 + 255) / 256) + ((ntw * 16 * 21 + 255) / 256)) * 256 * 16;
+    if (env_depth == 4 && 4 * slot <= 160 * 1024) {
+      if (ntw == 1) return lnf ? lds_mt<1, 20, 4, true, false, false>(ARGS) : lds_mt<1, 20, 4, false, false, false>(ARGS);
+      return lnf ? lds_mt<2, 20, 4, true, false, false>(ARGS) : lds_mt<2, 20, 4, false, false, false>(ARGS);
+    }
     if (ntw == 1) return lnf ? lds_mt<1, 20, 2, true, false, false>(ARGS) : lds_mt<1, 20, 2, false, false, false>(ARGS);
     return lnf ? lds_mt<2, 20, 2, true, false, false>(ARGS) : lds_mt<2, 20, 2, false, false, false>(ARGS);
   }
@@ -1207,9 +1218,14 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
                                                      pos_fixed, P, R_total);
 }
 
-void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int t_pad,
+void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div) {
-  dec_cross_attn_kernel<<<dim3(H, B), CA_WAVES * 64, 0, st>>>(qx, d, ck, cvt, T, t_pad, kmul, out, done, kv_div);
+  // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup; FWAMD_CA_WAVES=4 halves that
+  static const int waves = [] { const char* e = getenv("FWAMD_CA_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
+  if (waves == 4)
+    dec_cross_attn_kernel<4><<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div);
+  else
+    dec_cross_attn_kernel<8><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {
@@ -1236,9 +1252,10 @@ void launch_token_prob(hipStream_t st, const float* logits, int V, const int* ta
   dec_token_prob_kernel<<<rows, 1024, 0, st>>>(logits, V, target, out, out_stride, out_off);
 }
 
-void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, const int* heads,
+void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, int kvp, const int* heads,
                         int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B) {
-  dec_cross_probs_kernel<<<dim3(n_layer_heads, B), 256, 0, st>>>(qx, d, ck, T, heads, n_sel, probs, n_tok, tok_idx);
+  dec_cross_probs_kernel<<<dim3(n_layer_heads, B), 256, 0, st>>>(qx, d, ck, T, kvp, heads, n_sel, probs, n_tok,
+                                                                 tok_idx);
 }
 
 }  // namespace fwd

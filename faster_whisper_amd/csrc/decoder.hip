@@ -28,7 +28,8 @@ using fwd::GenDev;
 
 struct GenWorkspace {
   int B = 0, K = 0, R = 0, NT = 0;
-  half_t *ck = nullptr, *cvt = nullptr;  // K [L][B][H][T][64] (head-major), V^T [L][B][d][t_pad]
+  int kvp = 0;                           // encoder positions padded to the 32-key MFMA group
+  half_t *ck = nullptr, *cvt = nullptr;  // cross K / V^T [L][B][H][kvp*64], MFMA-fragment-major (dec_kernels.hip K14)
   uint64_t ckv_id = 0;                   // id of the encoder output the cross K/V belong to
   half_t *sk = nullptr, *sv = nullptr;   // [L][R][H][NT][64]
   half_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
@@ -66,13 +67,14 @@ int gen_workspace_create(Model* m) {
   g->K = m->max_beam;
   g->R = g->B * g->K;
   g->NT = c.n_text_ctx;
+  g->kvp = ((c.n_audio_ctx + 31) / 32) * 32;
   const size_t B = g->B, R = g->R, d = c.d_model, T = c.n_audio_ctx, L = c.n_dec_layers, NT = g->NT;
   const size_t Rg = std::max<size_t>(R, B);
   FW_CHECK_ARG(R <= 80, "max_batch * max_beam must be <= 80 (got %zu)", R);
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
-  A(g->ck, L * B * T * d);
-  A(g->cvt, L * B * d * m->t_pad);
+  A(g->ck, L * B * d * g->kvp);
+  A(g->cvt, L * B * d * g->kvp);
   A(g->sk, L * R * NT * d);
   A(g->sv, L * R * NT * d);
   A(g->x, Rg * d); A(g->xn, Rg * d); A(g->qkv, Rg * 3 * d); A(g->att, Rg * d); A(g->qc, Rg * d);
@@ -98,7 +100,9 @@ int gen_workspace_create(Model* m) {
     A(g->xs, Rg);
   }
 #undef A
-  FW_HIP(hipMemset(g->cvt, 0, L * B * d * m->t_pad * sizeof(half_t)));
+  // the padded keys (>= T) are never written: K garbage is masked, V^T must be 0 (0 * NaN)
+  FW_HIP(hipMemset(g->ck, 0, L * B * d * g->kvp * sizeof(half_t)));
+  FW_HIP(hipMemset(g->cvt, 0, L * B * d * g->kvp * sizeof(half_t)));
   FW_HIP(hipMemset(g->zero_done, 0, Rg * sizeof(int)));
   FW_HIP(hipMemset(g->d_step, 0, sizeof(int)));
   const char* ng = getenv("FWAMD_NO_GRAPH");
@@ -130,25 +134,24 @@ static int ensure_cross_kv(Model* m, const Tensor* enc) {
   int rc;
   ProfScope ps(m, PF_CROSS_KV_GEMM, 2.0 * c.n_dec_layers * B * (double)T * d * (2.0 * d), 0);
   const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
+  const int kvp = g->kvp;
+  const int64_t kvs = (int64_t)d * kvp;   // one chunk's K (or V^T): H heads x kvp keys x 64
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
-    half_t* kd = g->ck + (size_t)l * g->B * T * d;
-    half_t* vd = g->cvt + (size_t)l * g->B * d * m->t_pad;
+    half_t* kd = g->ck + (size_t)l * g->B * kvs;
+    half_t* vd = g->cvt + (size_t)l * g->B * kvs;
+    // both land in the MFMA-fragment-major layout of the decode kernel (head_rows = kvp selects it in the
+    // GEMM epilogue): K through the plain epilogue, V^T through the transposed one
     if (i8) {
       // the encoder output is quantised once (layer 0) and shared by all 2L projections
-      if ((rc = run_linear_i8(m, L.ck, l == 0 ? enc->data : nullptr, nullptr, kd, d, xs, nullptr, 0, 0, T, B, 0, false,
-                              T)))
+      if ((rc = run_linear_i8(m, L.ck, l == 0 ? enc->data : nullptr, nullptr, kd, d, kvs, nullptr, 0, 0, T, B, 0,
+                              false, kvp)))
         return rc;
-      if ((rc = run_linear_i8(m, L.cv, nullptr, nullptr, vd, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
-                              true, 0)))
-        return rc;
+      if ((rc = run_linear_i8(m, L.cv, nullptr, nullptr, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp))) return rc;
       continue;
     }
-    // K head-major [B][H][T][64]: the decode kernel then streams 192 KB contiguous per (chunk, head)
-    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, xs, nullptr, 0, 0, T, B, 0, false, T))) return rc;
-    if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, m->t_pad, (int64_t)d * m->t_pad, nullptr, 0, 0, T, B, 0,
-                         true)))
-      return rc;
+    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, kvs, nullptr, 0, 0, T, B, 0, false, kvp))) return rc;
+    if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp))) return rc;
   }
   g->ckv_id = enc->id;
   return FW_OK;
@@ -211,8 +214,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const DecLayerW& L = m->dec[l];
     half_t* kc = g->sk + (size_t)l * g->R * NT * d;
     half_t* vc = g->sv + (size_t)l * g->R * NT * d;
-    const half_t* ck = g->ck + (size_t)l * g->B * T * d;
-    const half_t* cvt = g->cvt + (size_t)l * g->B * d * m->t_pad;
+    const half_t* ck = g->ck + (size_t)l * g->B * d * g->kvp;
+    const half_t* cvt = g->cvt + (size_t)l * g->B * d * g->kvp;
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
       DG(lin(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
@@ -230,12 +233,12 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0);
       const int off = s.sel_layer_off[l], n = s.sel_layer_off[l + 1] - off;
-      fwd::launch_cross_probs(st, g->qc, d, ck, T, s.sel_heads_dev + off, n, s.n_sel_total,
+      fwd::launch_cross_probs(st, g->qc, d, ck, T, g->kvp, s.sel_heads_dev + off, n, s.n_sel_total,
                               s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
     }
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * s.B * (double)T * d);
-      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, m->t_pad, s.kmul, g->att, s.B, H, s.done, s.kv_div);
+      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, g->kvp, s.kmul, g->att, s.B, H, s.done, s.kv_div);
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d);

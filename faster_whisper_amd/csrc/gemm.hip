@@ -183,8 +183,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          half_t* dst = p.head_rows > 0 ? Cb + ((size_t)(n >> 6) * p.head_rows + m) * 64 + (n & 63)
-                                        : Cb + (size_t)m * p.ldc + n;
+          half_t* dst;
+          if (p.head_rows > 0) {
+            // cross-attention K, MFMA-fragment-major per (chunk, head): a 32-key group is 4 runs of 64 lanes x 16 B,
+            // run q = 2*sub + s, lane = 16*g + j  <->  key 32*gi + 8*(j>>2) + 4*sub + (j&3), dims 32*s + 8*g + [0,8)
+            const int c = n & 63, r = m & 31;
+            const int run = (m >> 5) * 4 + 2 * ((r >> 2) & 1) + (c >> 5);
+            const int ln = ((c >> 3) & 3) * 16 + (((r >> 3) << 2) | (r & 3));
+            dst = Cb + (size_t)(n >> 6) * p.head_rows * 64 + ((size_t)run * 64 + ln) * 8 + (c & 7);
+          } else {
+            dst = Cb + (size_t)m * p.ldc + n;
+          }
           *reinterpret_cast<half4_t*>(dst) = o;
         }
       }
@@ -209,7 +218,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
             if (p.act == 1) v = gelu_erf(v);
             o[e] = (half_t)v;
           }
-          half_t* dst = Cb + (size_t)n * p.ldc + m;
+          half_t* dst;
+          if (p.head_rows > 0) {
+            // cross-attention V^T, fragment-major per (chunk, head): run = 4*gi + dt, lane = 16*g + j  <->
+            // dim 16*dt + j, keys 32*gi + 8*g + [0,8)
+            const int c = n & 63;
+            dst = Cb + (size_t)(n >> 6) * p.head_rows * 64 +
+                  ((size_t)((m >> 5) * 4 + (c >> 4)) * 64 + ((m >> 3) & 3) * 16 + (c & 15)) * 8 + (m & 7);
+          } else {
+            dst = Cb + (size_t)n * p.ldc + m;
+          }
           if (m + 3 < p.M) {
             *reinterpret_cast<half4_t*>(dst) = o;
           } else {

@@ -22,7 +22,8 @@ struct GemmParams {
   half_t* C; int64_t ldc; int64_t c_bstride;          // C[z][m][n]   (TRANS: Ct[z][n][m], ldc = row stride)
   int M, N, K;
   int act;                                            // 0 none, 1 exact GELU
-  int head_rows;                                      // > 0: head-major output C[z][n/64][m][n%64] with head_rows rows per head
+  int head_rows;                                      // > 0: cross-attention K (plain) / V^T (TRANS) in MFMA-fragment-major
+                                                      // layout per 64-column head, head_rows = keys per head padded to 32
   // int8 path (a_scale != null): A and W point to int8 data; dequant scales per A row / per W row
   const float* a_scale; int64_t as_bstride; const float* w_scale;
   int nMt, nNt;                                       // filled by launch_gemm
