@@ -48,7 +48,7 @@ def _gemm_i8(model, A, W, bias=None, res=None, act=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 384), (300, 256, 128), (1500, 512, 512),
-                                   (77, 128, 256), (1500, 128, 512)])
+                                   (77, 128, 256), (1500, 128, 512), (1100, 256, 256)])
 def test_gemm_int8_exact(kmodel, M, N, K):
     rng = np.random.default_rng(M + 3 * N + K)
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
@@ -68,9 +68,9 @@ def test_gemm_int8_exact(kmodel, M, N, K):
     assert np.abs(out - full).max() / np.abs(full).max() < 5e-2
 
 
-def test_gemm_int8_transposed_epilogue(kmodel):
+@pytest.mark.parametrize("M,N,K", [(200, 128, 256), (1100, 256, 256)])   # one and many M tiles
+def test_gemm_int8_transposed_epilogue(kmodel, M, N, K):
     rng = np.random.default_rng(9)
-    M, N, K = 200, 128, 256
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
     W = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.3)
     b = _h(rng.standard_normal(N).astype(np.float32))

@@ -41,7 +41,9 @@ def _gemm(model, A, W, bias=None, res=None, act=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (300, 256, 128), (1500, 512, 1280),
-                                   (3000, 128, 384), (77, 128, 256)])
+                                   (3000, 128, 384), (77, 128, 256),
+                                   # many M tiles, ragged last tile
+                                   (1024, 256, 64), (1500, 768, 192), (1031, 256, 128)])
 def test_gemm_plain(model, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
@@ -54,9 +56,9 @@ def test_gemm_plain(model, M, N, K):
     assert err < 2e-3
 
 
-def test_gemm_epilogues(model):
+@pytest.mark.parametrize("M,N,K", [(200, 256, 192), (1100, 256, 192)])   # one and many M tiles
+def test_gemm_epilogues(model, M, N, K):
     rng = np.random.default_rng(5)
-    M, N, K = 200, 256, 192
     A = _h(rng.standard_normal((M, K)).astype(np.float32) * 0.5)
     W = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.2)
     b = _h(rng.standard_normal(N).astype(np.float32))
@@ -69,9 +71,9 @@ def test_gemm_epilogues(model):
         assert err < 2e-2 * max(1.0, np.abs(ref).max() / 4)
 
 
-def test_gemm_transposed_output(model):
+@pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1500, 256, 128), (1027, 512, 64)])
+def test_gemm_transposed_output(model, M, N, K):
     rng = np.random.default_rng(6)
-    M, N, K = 300, 128, 128
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
     W = _h(rng.standard_normal((N, K)).astype(np.float32))
     b = _h(rng.standard_normal(N).astype(np.float32))
