@@ -794,9 +794,13 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
     const int nt = ntok[b] - n0 - 1;
     out_n_pairs[b] = 0;
     for (int i = 0; i < nt; ++i) out_probs[text_offsets[b] + i] = htprob[(size_t)b * max_tok + (n0 - 1 + i)];
-    if (nt <= 0) continue;
+    if (nt < 0) continue;
+    // rows of the cost matrix: positions n_start .. n_start + nt (the <|notimestamps|> position, whose
+    // attention predicts the first text token, up to the last text token; the <|endoftext|> row is dropped)
+    // = nt + 1 rows, like openai-whisper's matrix[len(sot_sequence):-1].  The reference indexes the path's
+    // token jumps with word boundaries up to nt (transcribe.py:1741-1745), so it needs exactly these rows.
     std::vector<int> ti, fi;
-    fw::dtw_path(&hmat[((size_t)b * max_tok + n0) * T], T, nt, nfr[b], ti, fi);
+    fw::dtw_path(&hmat[((size_t)b * max_tok + n_start) * T], T, nt + 1, nfr[b], ti, fi);
     const int np = std::min((int)ti.size(), max_pairs);
     for (int i = 0; i < np; ++i) {
       out_pairs[((size_t)b * max_pairs + i) * 2] = ti[i];

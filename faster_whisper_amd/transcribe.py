@@ -13,9 +13,14 @@ but is written for this engine: features are computed on the GPU, the backend is
 `faster_whisper_amd.backend.Whisper`, and `transcribe(..., shard=True)` partitions the chunk
 list over the ranks of a torch.distributed job.
 
-Out of scope for this tier: the sequential seek loop
-(`WhisperModel.transcribe`), Silero VAD, PyAV decoding, the word-timestamp heuristics.  The
-reference's own host code runs unchanged on top of `faster_whisper_amd.ct2_shim` for those.
+Also here: the sequential seek loop
+(`WhisperModel.transcribe` / `generate_segments` :747-1022, :1103-1389), the temperature-fallback ladder
+(`generate_with_fallback` :1402-1530) and word timestamps (`add_word_timestamps` :1567-1696; heuristics in
+words.py, speech chunking in vad.py).  The host logic is pinned against the reference's own code driven by a
+scripted backend (oracle/gen_golden_host.py -> tests/golden/host_*.json).
+
+Out of scope: the Silero VAD network itself (row f-3: speech probabilities are an input
+here) and PyAV decoding (row f-4: audio is a 16 kHz float32 ndarray).
 """
 import json
 import logging
@@ -198,9 +203,66 @@ class Tokenizer:
 
     def decode(self, tokens: List[int]) -> str:
         text_tokens = [t for t in tokens if t < self.eot]
+        return self._render(text_tokens)
+
+    def _render(self, ids: List[int]) -> str:
+        """text of a run of non-timestamp ids (special tokens are dropped, as HF `decode` does)"""
         if self.tokenizer is None:
-            return "".join(f"<{t}>" for t in text_tokens)
-        return self.tokenizer.decode(text_tokens)
+            return "".join(f"<{t}>" for t in ids if t < self.eot)
+        return self.tokenizer.decode(ids)
+
+    def decode_with_timestamps(self, tokens: List[int]) -> str:
+        """text with every timestamp token rendered as <|s.ss|> (tokenizer.py:95-112)"""
+        out, run = [], []
+        for t in tokens:
+            if t >= self.timestamp_begin:
+                out.append(self._render(run))
+                out.append(f"<|{(t - self.timestamp_begin) * 0.02:.2f}|>")
+                run = []
+            else:
+                run.append(t)
+        out.append(self._render(run))
+        return "".join(out)
+
+    # ---- word splitting (tokenizer.py:150-208) -------------------------------------------
+    def split_to_word_tokens(self, tokens: List[int]) -> Tuple[List[str], List[List[int]]]:
+        # languages written without spaces are split wherever the bytes so far decode to whole characters
+        if self.language_code in {"zh", "ja", "th", "lo", "my", "yue"}:
+            return self.split_tokens_on_unicode(tokens)
+        return self.split_tokens_on_spaces(tokens)
+
+    def split_tokens_on_unicode(self, tokens: List[int]) -> Tuple[List[str], List[List[int]]]:
+        """groups tokens until they decode without a dangling partial UTF-8 sequence (U+FFFD), unless the
+        full text really has U+FFFD at that position"""
+        full = self.decode_with_timestamps(tokens)
+        words, groups, pending, consumed = [], [], [], 0
+        for t in tokens:
+            pending.append(t)
+            text = self.decode_with_timestamps(pending)
+            bad = text.find("�")
+            if bad < 0 or (consumed + bad < len(full) and full[consumed + bad] == "�"):
+                words.append(text)
+                groups.append(pending)
+                consumed += len(text)
+                pending = []
+        return words, groups
+
+    def split_tokens_on_spaces(self, tokens: List[int]) -> Tuple[List[str], List[List[int]]]:
+        """unicode pieces are joined into words: a piece opens a new word when it is a special token, starts
+        with a space, is a lone punctuation mark, or is the very first piece"""
+        import string
+        words: List[str] = []
+        groups: List[List[int]] = []
+        for piece, ids in zip(*self.split_tokens_on_unicode(tokens)):
+            opens = (ids[0] >= self.eot or piece.startswith(" ") or piece.strip() in string.punctuation
+                     or not words)
+            if opens:
+                words.append(piece)
+                groups.append(ids)
+            else:
+                words[-1] += piece
+                groups[-1].extend(ids)
+        return words, groups
 
 
 def get_suppressed_tokens(tokenizer: Tokenizer, suppress_tokens) -> Optional[Tuple[int, ...]]:
@@ -275,10 +337,278 @@ class WhisperModel:
             self.logger.warning("Could not load preprocessor config: %s", e)
         return config
 
-    def transcribe(self, *args, **kwargs):
-        raise NotImplementedError(
-            "the sequential seek-loop path is outside this tier's hot path (SURVEY.md section 2): use "
-            "BatchedInferencePipeline.transcribe, or run the reference's WhisperModel on faster_whisper_amd.ct2_shim")
+    # ---- sequential path (reference transcribe.py:747-1022, :1103-1389) ----
+    def transcribe(self, audio: np.ndarray, language: Optional[str] = None, task: str = "transcribe",
+                   log_progress: bool = False, beam_size: int = 5, best_of: int = 5, patience: float = 1,
+                   length_penalty: float = 1, repetition_penalty: float = 1, no_repeat_ngram_size: int = 0,
+                   temperature=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), compression_ratio_threshold: Optional[float] = 2.4,
+                   log_prob_threshold: Optional[float] = -1.0, no_speech_threshold: Optional[float] = 0.6,
+                   condition_on_previous_text: bool = True, prompt_reset_on_temperature: float = 0.5,
+                   initial_prompt=None, prefix: Optional[str] = None, suppress_blank: bool = True,
+                   suppress_tokens: Optional[List[int]] = [-1], without_timestamps: bool = False,
+                   max_initial_timestamp: float = 1.0, word_timestamps: bool = False,
+                   prepend_punctuations: str = "\"'“¿([{-", append_punctuations: str = "\"'.。,，!！?？:：”)]}、",
+                   multilingual: bool = False, vad_filter: bool = False, vad_parameters=None,
+                   max_new_tokens: Optional[int] = None, chunk_length: Optional[int] = None,
+                   clip_timestamps: Union[str, List[float]] = "0",
+                   hallucination_silence_threshold: Optional[float] = None, hotwords: Optional[str] = None,
+                   language_detection_threshold: Optional[float] = 0.5, language_detection_segments: int = 1,
+                   vad_speech_probs=None):
+        """Sequential (seek-loop) transcription: 30 s windows decoded one after the other, each conditioned on
+        the text before it, with the temperature-fallback ladder.  Same arguments / defaults / return value
+        as the reference's WhisperModel.transcribe; `vad_speech_probs` feeds vad.get_speech_timestamps while
+        the Silero network (row f-3) is not built."""
+        from .vad import VadOptions, collect_chunks, get_speech_timestamps
+        from .words import restore_speech_timestamps
+        sr = self.feature_extractor.sampling_rate
+        if multilingual and not self.model.is_multilingual:
+            self.logger.warning("The current model is English-only but the multilingual parameter is set to"
+                                "True; setting to False instead.")
+            multilingual = False
+        if not isinstance(audio, np.ndarray):
+            raise NotImplementedError("audio decoding (PyAV) is outside this tier: pass a 16 kHz float32 ndarray")
+        duration = audio.shape[0] / sr
+        duration_after_vad = duration
+        speech_chunks = None
+        if vad_filter and clip_timestamps == "0":
+            if vad_parameters is None:
+                vad_parameters = VadOptions()
+            elif isinstance(vad_parameters, dict):
+                vad_parameters = VadOptions(**vad_parameters)
+            speech_chunks = get_speech_timestamps(audio, vad_parameters, speech_probs=vad_speech_probs)
+            audio_chunks, _ = collect_chunks(audio, speech_chunks)
+            audio = np.concatenate(audio_chunks, axis=0)
+            duration_after_vad = audio.shape[0] / sr
+        features = self.feature_extractor(audio, chunk_length=chunk_length)
+
+        all_language_probs = None
+        if language is None:
+            if not self.model.is_multilingual:
+                language, language_probability = "en", 1
+            else:
+                first = float(clip_timestamps.split(",")[0]) if isinstance(clip_timestamps, str) else clip_timestamps[0]
+                content_frames = features.shape[-1] - 1
+                at = first * self.frames_per_second
+                seek = int(at) if at < content_frames else 0
+                language, language_probability, all_language_probs = self.detect_language(
+                    features=features[..., seek:], language_detection_segments=language_detection_segments,
+                    language_detection_threshold=language_detection_threshold)
+        else:
+            if not self.model.is_multilingual and language != "en":
+                self.logger.warning("The current model is English-only but the language parameter is set to '%s'; "
+                                    "using 'en' instead." % language)
+                language = "en"
+            language_probability = 1
+        tokenizer = self.make_tokenizer(task=task, language=language)
+        options = TranscriptionOptions(
+            beam_size=beam_size, best_of=best_of, patience=patience, length_penalty=length_penalty,
+            repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
+            log_prob_threshold=log_prob_threshold, no_speech_threshold=no_speech_threshold,
+            compression_ratio_threshold=compression_ratio_threshold,
+            condition_on_previous_text=condition_on_previous_text,
+            prompt_reset_on_temperature=prompt_reset_on_temperature,
+            temperatures=(temperature if isinstance(temperature, (list, tuple)) else [temperature]),
+            initial_prompt=initial_prompt, prefix=prefix, suppress_blank=suppress_blank,
+            suppress_tokens=(get_suppressed_tokens(tokenizer, suppress_tokens) if suppress_tokens
+                             else suppress_tokens),
+            without_timestamps=without_timestamps, max_initial_timestamp=max_initial_timestamp,
+            word_timestamps=word_timestamps, prepend_punctuations=prepend_punctuations,
+            append_punctuations=append_punctuations, multilingual=multilingual, max_new_tokens=max_new_tokens,
+            clip_timestamps=clip_timestamps, hallucination_silence_threshold=hallucination_silence_threshold,
+            hotwords=hotwords)
+        segments = self.generate_segments(features, tokenizer, options, log_progress, None)
+        if speech_chunks:
+            segments = restore_speech_timestamps(segments, speech_chunks, sr)
+        info = TranscriptionInfo(language=language, language_probability=language_probability, duration=duration,
+                                 duration_after_vad=duration_after_vad, transcription_options=options,
+                                 vad_options=vad_parameters, all_language_probs=all_language_probs)
+        return segments, info
+
+    def generate_segments(self, features: np.ndarray, tokenizer: Tokenizer, options: TranscriptionOptions,
+                          log_progress: bool = False, encoder_output: Optional[StorageView] = None):
+        """The seek loop (generator of Segment).  For every clip [start, end) of `options.clip_timestamps`
+        (frames; an odd count runs to the end of the audio) windows of up to 30 s are decoded at `seek`;
+        the timestamps the model emitted (or the last word's end, or a hallucination-silence skip) decide
+        where the next window starts."""
+        from .words import get_end, is_segment_anomaly, next_words_segment
+        fe = self.feature_extractor
+        tpf, fps = fe.time_per_frame, self.frames_per_second
+        content_frames = features.shape[-1] - 1
+        content_duration = float(content_frames * tpf)
+        if isinstance(options.clip_timestamps, str):
+            options.clip_timestamps = [float(x) for x in options.clip_timestamps.split(",")] \
+                if options.clip_timestamps else []
+        marks = [round(t * fps) for t in options.clip_timestamps] or [0]
+        if len(marks) % 2 == 1:
+            marks.append(content_frames)
+        clips = list(zip(marks[::2], marks[1::2]))
+
+        all_tokens: List[int] = []
+        prompt_reset_since = 0
+        if options.initial_prompt is not None:
+            if isinstance(options.initial_prompt, str):
+                all_tokens.extend(tokenizer.encode(" " + options.initial_prompt.strip()))
+            else:
+                all_tokens.extend(options.initial_prompt)
+        pbar = None
+        if log_progress:
+            from tqdm import tqdm
+            pbar = tqdm(total=content_duration, unit="seconds")
+        idx = 0
+        last_speech_timestamp = 0.0
+        for clip_start, clip_end in clips:
+            clip_end = min(clip_end, content_frames)
+            seek = clip_start
+            while True:
+                seek = max(seek, clip_start)
+                if seek >= clip_end:
+                    break
+                previous_seek = seek
+                time_offset = seek * tpf
+                window_end_time = float((seek + fe.nb_max_frames) * tpf)
+                segment_size = min(fe.nb_max_frames, content_frames - seek, clip_end - seek)
+                segment_duration = segment_size * tpf
+                window = pad_or_trim(features[:, seek:seek + segment_size])
+                previous_tokens = all_tokens[prompt_reset_since:]
+                if seek > 0 or encoder_output is None:
+                    encoder_output = self.encode(window)
+                if options.multilingual:
+                    language_token, _ = self.model.detect_language(encoder_output)[0][0]
+                    names = language_token_strings(self.model.config)
+                    tokenizer.language = self.model.config.lang_begin + names.index(language_token)
+                    tokenizer.language_code = language_token[2:-2]
+                prompt = self.get_prompt(tokenizer, previous_tokens, without_timestamps=options.without_timestamps,
+                                         prefix=options.prefix if seek == 0 else None, hotwords=options.hotwords)
+                result, avg_logprob, temperature, compression_ratio = self.generate_with_fallback(
+                    encoder_output, prompt, tokenizer, options)
+
+                if options.no_speech_threshold is not None:
+                    skip = result.no_speech_prob > options.no_speech_threshold
+                    if options.log_prob_threshold is not None and avg_logprob > options.log_prob_threshold:
+                        skip = False            # confident text beats the no-speech probability
+                    if skip:
+                        seek += segment_size    # fast-forward to the next window
+                        continue
+
+                tokens = result.sequences_ids[0]
+                current, seek, single_timestamp_ending = self._split_segments_by_timestamps(
+                    tokenizer=tokenizer, tokens=tokens, time_offset=time_offset, segment_size=segment_size,
+                    segment_duration=segment_duration, seek=seek)
+
+                if options.word_timestamps:
+                    self.add_word_timestamps([current], tokenizer, encoder_output, segment_size,
+                                             options.prepend_punctuations, options.append_punctuations,
+                                             last_speech_timestamp=last_speech_timestamp)
+                    if not single_timestamp_ending:
+                        last_word_end = get_end(current)
+                        if last_word_end is not None and last_word_end > time_offset:
+                            seek = round(last_word_end * fps)
+                    threshold = options.hallucination_silence_threshold
+                    if threshold is not None:
+                        # leading silence before a probable hallucination: re-decode from where speech starts
+                        first = next_words_segment(current)
+                        if first is not None and is_segment_anomaly(first):
+                            gap = first["start"] - time_offset
+                            if gap > threshold:
+                                seek = previous_seek + round(gap * fps)
+                                continue
+                        # a probable hallucination surrounded by silence (or more of them): cut there
+                        hal_last_end = last_speech_timestamp
+                        for si, seg in enumerate(current):
+                            if not seg["words"]:
+                                continue
+                            if is_segment_anomaly(seg):
+                                nxt = next_words_segment(current[si + 1:])
+                                hal_next_start = nxt["words"][0]["start"] if nxt is not None \
+                                    else time_offset + segment_duration
+                                silence_before = (seg["start"] - hal_last_end > threshold or seg["start"] < threshold
+                                                  or seg["start"] - time_offset < 2.0)
+                                silence_after = (hal_next_start - seg["end"] > threshold or is_segment_anomaly(nxt)
+                                                 or window_end_time - seg["end"] < 2.0)
+                                if silence_before and silence_after:
+                                    seek = round(max(time_offset + 1, seg["start"]) * fps)
+                                    if content_duration - seg["end"] < threshold:
+                                        seek = content_frames
+                                    current[si:] = []
+                                    break
+                            hal_last_end = seg["end"]
+                    last_word_end = get_end(current)
+                    if last_word_end is not None:
+                        last_speech_timestamp = last_word_end
+
+                for seg in current:
+                    text = tokenizer.decode(seg["tokens"])
+                    if seg["start"] == seg["end"] or not text.strip():
+                        continue
+                    all_tokens.extend(seg["tokens"])
+                    idx += 1
+                    yield Segment(id=idx, seek=previous_seek, start=seg["start"], end=seg["end"], text=text,
+                                  tokens=seg["tokens"], temperature=temperature, avg_logprob=avg_logprob,
+                                  compression_ratio=compression_ratio, no_speech_prob=result.no_speech_prob,
+                                  words=([Word(**w) for w in seg["words"]] if options.word_timestamps else None))
+
+                if not options.condition_on_previous_text or temperature > options.prompt_reset_on_temperature:
+                    prompt_reset_since = len(all_tokens)
+                if pbar is not None:
+                    pbar.update((min(content_frames, seek) - previous_seek) * tpf)
+        if pbar is not None:
+            pbar.close()
+
+    def generate_with_fallback(self, encoder_output: StorageView, prompt: List[int], tokenizer: Tokenizer,
+                               options: TranscriptionOptions):
+        """Temperature ladder (transcribe.py:1402-1530): beam search at t = 0, `best_of` random samples at
+        t > 0; a result is accepted unless it is too repetitive (compression ratio) or too improbable
+        (average log-prob) — except when it looks like silence.  If every temperature fails, the most probable
+        attempt (preferring those under the compression threshold) is returned with the last temperature.
+        -> (WhisperGenerationResult, avg_logprob, temperature, compression_ratio)"""
+        max_initial_timestamp_index = int(round(options.max_initial_timestamp / self.time_precision))
+        max_length = len(prompt) + options.max_new_tokens if options.max_new_tokens is not None else self.max_length
+        if max_length > self.max_length:
+            raise ValueError(
+                f"The length of the prompt is {len(prompt)}, and the `max_new_tokens` {max_length - len(prompt)}. "
+                f"Thus, the combined length of the prompt and `max_new_tokens` is: {max_length}. This exceeds the "
+                f"`max_length` of the Whisper model: {self.max_length}. You should either reduce the length of your "
+                f"prompt, or reduce the value of `max_new_tokens`, so that their combined length is less that "
+                f"{self.max_length}.")
+        attempts, compact = [], []
+        chosen = None
+        for temperature in options.temperatures:
+            if temperature > 0:
+                mode = dict(beam_size=1, num_hypotheses=options.best_of, sampling_topk=0,
+                            sampling_temperature=temperature)
+            else:
+                mode = dict(beam_size=options.beam_size, patience=options.patience)
+            result = self.model.generate(
+                encoder_output, [prompt], length_penalty=options.length_penalty,
+                repetition_penalty=options.repetition_penalty, no_repeat_ngram_size=options.no_repeat_ngram_size,
+                max_length=max_length, return_scores=True, return_no_speech_prob=True,
+                suppress_blank=options.suppress_blank, suppress_tokens=options.suppress_tokens,
+                max_initial_timestamp_index=max_initial_timestamp_index, **mode)[0]
+            tokens = result.sequences_ids[0]
+            n = len(tokens)
+            avg_logprob = result.scores[0] * (n ** options.length_penalty) / (n + 1)   # undo the length norm
+            compression_ratio = get_compression_ratio(tokenizer.decode(tokens).strip())
+            attempt = (result, avg_logprob, temperature, compression_ratio)
+            attempts.append(attempt)
+            retry = False
+            if options.compression_ratio_threshold is not None:
+                if compression_ratio > options.compression_ratio_threshold:
+                    retry = True
+                else:
+                    compact.append(attempt)
+            low_prob = options.log_prob_threshold is not None and avg_logprob < options.log_prob_threshold
+            if low_prob:
+                retry = True
+            if options.no_speech_threshold is not None and result.no_speech_prob > options.no_speech_threshold \
+                    and low_prob:
+                retry = False                   # silence: a colder decode will not help
+            if not retry:
+                chosen = attempt
+                break
+        if chosen is None:
+            best = max(compact or attempts, key=lambda a: a[1])
+            chosen = (best[0], best[1], temperature, best[3])   # last temperature drives the prompt reset
+        return chosen
 
     def make_tokenizer(self, task="transcribe", language="en") -> Tokenizer:
         return Tokenizer(self.hf_tokenizer, self.model.config, self.model.is_multilingual, task=task, language=language)
@@ -344,22 +674,37 @@ class WhisperModel:
 
     def find_alignment(self, tokenizer: Tokenizer, text_tokens: List[List[int]], encoder_output: StorageView,
                        num_frames, median_filter_width: int = 7) -> List[dict]:
-        """raw per-token alignment from the backend (transcribe.py:1698-1746): for each chunk the token
-        jump times and token probabilities; the word grouping heuristics stay with the reference host code."""
+        """per chunk: the words {word, tokens, start, end, probability} of its text tokens, timed by the
+        backend's cross-attention DTW (transcribe.py:1698-1766).  `num_frames`: int or one int per chunk."""
+        from .words import word_alignment
         if len(text_tokens) == 0:
             return []
         results = self.model.align(encoder_output, tokenizer.sot_sequence, text_tokens, num_frames,
                                    median_filter_width=median_filter_width)
-        out = []
-        for res in results:
-            if not res.alignments:
-                out.append(dict(jump_times=np.zeros(0), text_token_probs=[]))
-                continue
-            ti = np.array([p[0] for p in res.alignments])
-            fi = np.array([p[1] for p in res.alignments])
-            jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
-            out.append(dict(jump_times=fi[jumps] / self.tokens_per_second, text_token_probs=res.text_token_probs))
-        return out
+        return [word_alignment(tokenizer, toks, res.alignments, res.text_token_probs, self.tokens_per_second)
+                for res, toks in zip(results, text_tokens)]
+
+    def add_word_timestamps(self, segments: List[List[dict]], tokenizer: Tokenizer, encoder_output: StorageView,
+                            num_frames, prepend_punctuations: str, append_punctuations: str,
+                            last_speech_timestamp: float) -> float:
+        """`segments`: per chunk, the list of its sub-segment dicts (seek/start/end/tokens).  Aligns every
+        chunk's text tokens in ONE backend call, merges punctuation into neighbouring words, clamps
+        over-long words at sentence / pause / segment boundaries and stores `words` in every sub-segment
+        (transcribe.py:1567-1696).  -> end time of the last word (carried into the next call)."""
+        from .words import assign_words, clamp_sentence_boundaries, merge_punctuations
+        if len(segments) == 0:
+            return None
+        per_sub = [[[t for t in sub["tokens"] if t < tokenizer.eot] for sub in chunk] for chunk in segments]
+        text_tokens = [[t for sub in subs for t in sub] for subs in per_sub]
+        alignments = self.find_alignment(tokenizer, text_tokens, encoder_output, num_frames)
+        limits = []
+        for alignment in alignments:
+            limits.append(clamp_sentence_boundaries(alignment))
+            merge_punctuations(alignment, prepend_punctuations, append_punctuations)
+        for chunk, subs, alignment, (median, longest) in zip(segments, per_sub, alignments, limits):
+            last_speech_timestamp = assign_words(chunk, alignment, subs, chunk[0]["seek"] / self.frames_per_second,
+                                                 median, longest, last_speech_timestamp)
+        return last_speech_timestamp
 
     def detect_language(self, audio: Optional[np.ndarray] = None, features: Optional[np.ndarray] = None,
                         vad_filter: bool = False, vad_parameters=None, language_detection_segments: int = 1,
@@ -454,9 +799,12 @@ class BatchedInferencePipeline:
                      seek=int(meta["offset"] * m.frames_per_second))
                 for s in subs])
         if options.word_timestamps:
-            raise NotImplementedError(
-                "word_timestamps needs the reference's add_word_timestamps heuristics (out of scope for this tier); "
-                "WhisperModel.find_alignment exposes the backend alignment")
+            if encoder_output is None:
+                raise NotImplementedError("word_timestamps with shard=True: the alignment needs the encoder output "
+                                          "of the rank that decoded the chunk (not gathered yet)")
+            self.last_speech_timestamp = m.add_word_timestamps(
+                segmented, tokenizer, encoder_output, sizes, options.prepend_punctuations,
+                options.append_punctuations, self.last_speech_timestamp)
         return segmented
 
     # ---- the public entry point ---------------------------------------------------------
@@ -475,7 +823,7 @@ class BatchedInferencePipeline:
                    clip_timestamps: Optional[List[dict]] = None, hallucination_silence_threshold=None,
                    batch_size: int = 8, hotwords: Optional[str] = None,
                    language_detection_threshold: Optional[float] = 0.5, language_detection_segments: int = 1,
-                   shard: bool = False, fused_features: bool = True):
+                   shard: bool = False, fused_features: bool = True, vad_speech_probs=None):
         """Same contract as the reference (transcribe.py:254-578): returns (segment generator, info).
         shard=True: inside a torch.distributed job every rank calls this with the same arguments; the
         chunk list is block-partitioned over the ranks and rank 0's generator yields ALL segments in
@@ -492,33 +840,55 @@ class BatchedInferencePipeline:
         audio = np.asarray(audio, dtype=np.float32)
         duration = audio.shape[0] / sr
         chunk_length = chunk_length or m.feature_extractor.chunk_length
-        if not clip_timestamps:
-            if duration < chunk_length:
-                clip_timestamps = [{"start": 0.0, "end": duration}]
-            elif vad_filter:
-                raise NotImplementedError(
-                    "Silero VAD chunking is a 'next' row of this tier (SURVEY.md section 8f-3): provide "
-                    "clip_timestamps=[{'start': s, 'end': e}, ...] (seconds)")
+        from .vad import VadOptions, collect_chunks, get_speech_timestamps
+        from .words import restore_speech_timestamps
+        clips_given = bool(clip_timestamps)
+        if not clips_given:
+            # no split provided: speech spans from the VAD (merged into <= chunk_length chunks), or the whole
+            # audio when it is shorter than one chunk
+            if vad_filter:
+                if vad_parameters is None:
+                    vad_parameters = VadOptions(max_speech_duration_s=chunk_length, min_silence_duration_ms=160)
+                elif isinstance(vad_parameters, dict):
+                    vad_parameters = VadOptions(**{k: v for k, v in vad_parameters.items()
+                                                   if k != "max_speech_duration_s"},
+                                                max_speech_duration_s=chunk_length)
+                clips = get_speech_timestamps(audio, vad_parameters, speech_probs=vad_speech_probs)
+            elif duration < chunk_length:
+                clips = [{"start": 0, "end": audio.shape[0]}]
             else:
                 raise RuntimeError("No clip timestamps found. Set 'vad_filter' to True or provide 'clip_timestamps'.")
-        clips = [{k: int(v * sr) for k, v in seg.items()} for seg in clip_timestamps]
-        audio_chunks, chunks_metadata = [], []
-        for i, clip in enumerate(clips):
-            audio_chunks.append(audio[clip["start"]:clip["end"]])
-            d = (clip["end"] - clip["start"]) / sr
-            if d > 30:
-                m.logger.warning("Segment %d is longer than 30 seconds, only the first 30 seconds will be "
-                                 "transcribed", i)
-            chunks_metadata.append({"offset": clip["start"] / sr, "duration": d, "segments": [clip]})
+            audio_chunks, chunks_metadata = collect_chunks(audio, clips, max_duration=chunk_length)
+        else:
+            clips = [{k: int(v * sr) for k, v in seg.items()} for seg in clip_timestamps]
+            audio_chunks, chunks_metadata = [], []
+            for i, clip in enumerate(clips):
+                audio_chunks.append(audio[clip["start"]:clip["end"]])
+                d = (clip["end"] - clip["start"]) / sr
+                if d > 30:
+                    m.logger.warning("Segment %d is longer than 30 seconds, only the first 30 seconds will be "
+                                     "transcribed", i)
+                chunks_metadata.append({"offset": clip["start"] / sr, "duration": d, "segments": [clip]})
         duration_after_vad = sum(c["end"] - c["start"] for c in clips) / sr
+        if not duration_after_vad:
+            audio_chunks, chunks_metadata = [], []
 
         all_language_probs = None
         if language is None:
             if not m.model.is_multilingual:
                 language, language_probability = "en", 1
             else:
-                feats = np.concatenate([m.model.log_mel(audio_chunks[:1])[0]]
-                                       + [np.full((m.model.n_mels, 1), -1.5, dtype="float32")], axis=1)
+                # the reference concatenates the (unpadded) features of ALL chunks; detect_language only looks
+                # at the first language_detection_segments * 3000 frames, so stop once those are covered
+                need = language_detection_segments * m.feature_extractor.nb_max_frames
+                parts, have = [], 0
+                for chunk in audio_chunks:
+                    if have >= need:
+                        break
+                    parts.append(m.feature_extractor(chunk)[..., :-1])
+                    have += parts[-1].shape[-1]
+                # + one dummy frame so that empty audio still has a feature
+                feats = np.concatenate(parts + [np.full((m.model.n_mels, 1), -1.5, dtype="float32")], axis=1)
                 language, language_probability, all_language_probs = m.detect_language(
                     features=feats, language_detection_segments=language_detection_segments,
                     language_detection_threshold=language_detection_threshold)
@@ -541,13 +911,16 @@ class BatchedInferencePipeline:
             prepend_punctuations=prepend_punctuations, append_punctuations=append_punctuations,
             max_new_tokens=max_new_tokens, hotwords=hotwords, word_timestamps=word_timestamps,
             hallucination_silence_threshold=None, condition_on_previous_text=False,
-            clip_timestamps=clip_timestamps, prompt_reset_on_temperature=0.5, multilingual=multilingual,
+            clip_timestamps=(clip_timestamps if clips_given else clips), prompt_reset_on_temperature=0.5,
+            multilingual=multilingual,
             without_timestamps=without_timestamps, max_initial_timestamp=0.0)
         info = TranscriptionInfo(language=language, language_probability=language_probability, duration=duration,
                                  duration_after_vad=duration_after_vad, transcription_options=options,
                                  vad_options=vad_parameters, all_language_probs=all_language_probs)
         gen = self._batched_segments_generator(audio_chunks, tokenizer, chunks_metadata, batch_size, options,
                                                log_progress, shard, fused_features)
+        if not clips_given:
+            gen = restore_speech_timestamps(gen, clips, sr)
         return gen, info
 
     def _batched_segments_generator(self, audio_chunks, tokenizer, chunks_metadata, batch_size, options,
@@ -560,10 +933,29 @@ class BatchedInferencePipeline:
             rank, world = dist.get_rank(), dist.get_world_size()
             local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         n = len(audio_chunks)
+        seg_idx = 0
+        if world == 1:
+            # single process: batch by batch, segments are yielded as soon as their batch is decoded
+            for i in range(0, n, batch_size):
+                chunks = audio_chunks[i:i + batch_size]
+                feats = None if fused_features else m.model.log_mel(chunks)
+                results = self.forward(feats, tokenizer, chunks_metadata[i:i + batch_size], options,
+                                       audio_chunks=chunks if fused_features else None)
+                for result in results:
+                    for seg in result:
+                        seg_idx += 1
+                        yield Segment(seek=seg["seek"], id=seg_idx, text=seg["text"], start=round(seg["start"], 3),
+                                      end=round(seg["end"], 3), tokens=seg["tokens"], avg_logprob=seg["avg_logprob"],
+                                      words=(None if not options.word_timestamps
+                                             else [Word(**w) for w in seg["words"]]),
+                                      no_speech_prob=seg["no_speech_prob"],
+                                      compression_ratio=seg["compression_ratio"],
+                                      temperature=options.temperatures[0])
+            self.last_speech_timestamp = 0.0
+            return
         bounds = partition(n, world)
         lo, hi = bounds[rank]
         max_len = m.max_length
-        seg_idx = 0
         # every rank walks the same number of batch rounds so the per-round gather lines up
         rounds = max((b[1] - b[0] + batch_size - 1) // batch_size for b in bounds) if n else 0
         per_rank_outputs = [[] for _ in range(world)]

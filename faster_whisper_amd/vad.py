@@ -1,0 +1,179 @@
+"""Host-side speech chunking of the batched path (next-row f-3 for the network).
+
+Mirrors the reference's `faster_whisper/vad.py` interface (same names, argument meaning, return layout):
+    VadOptions                      vad.py:14-43
+    get_speech_timestamps           vad.py:46-183   hysteresis state machine over per-window speech probabilities
+    collect_chunks                  vad.py:186-243  merge speech spans into <= max_duration chunks
+    SpeechTimestampsMap             vad.py:246-285  map times on the silence-free axis back to the recording
+
+The Silero VAD v6 network that produces the window probabilities (vad.py:295-351, an ONNX asset run by
+onnxruntime on one CPU thread in the reference) is row f-3 and not built: `get_speech_timestamps` takes the
+probabilities from `speech_probs=` or from a callable `vad_model=` (same contract as the reference's
+SileroVADModel.__call__: padded audio -> one probability per 512-sample window) and fails loudly otherwise.
+Everything downstream of the probabilities is integer/host logic and is complete.
+"""
+import bisect
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+WINDOW = 512   # samples per VAD window at 16 kHz (vad.py:70)
+
+
+@dataclass
+class VadOptions:
+    """threshold: probability at/above which a window is speech; neg_threshold: below it a triggered span starts
+    counting silence (default threshold - 0.15, floor 0.01); min_speech_duration_ms: shorter spans are dropped;
+    max_speech_duration_s: longer spans are cut at the last >98 ms silence (or hard); min_silence_duration_ms:
+    silence needed to close a span; speech_pad_ms: padding on both sides of every span."""
+    threshold: float = 0.5
+    neg_threshold: Optional[float] = None
+    min_speech_duration_ms: int = 0
+    max_speech_duration_s: float = float("inf")
+    min_silence_duration_ms: int = 2000
+    speech_pad_ms: int = 400
+
+
+def get_speech_timestamps(audio: np.ndarray, vad_options: Optional[VadOptions] = None, sampling_rate: int = 16000,
+                          speech_probs: Optional[Sequence[float]] = None,
+                          vad_model: Optional[Callable[[np.ndarray], np.ndarray]] = None, **kwargs) -> List[dict]:
+    """-> [{"start": sample, "end": sample}, ...] speech spans of `audio` (1-D float array)."""
+    opts = vad_options if vad_options is not None else VadOptions(**kwargs)
+    n_audio = len(audio)
+    if speech_probs is None:
+        if vad_model is None:
+            raise RuntimeError("the Silero VAD network is not built in this tier (SURVEY.md section 8f-3): pass "
+                               "speech_probs= (one probability per 512-sample window) or vad_model=, or give "
+                               "clip_timestamps to transcribe()")
+        # the reference always appends 1..512 zero samples (a whole extra window when already aligned)
+        padded = np.pad(audio, (0, WINDOW - n_audio % WINDOW))
+        speech_probs = vad_model(padded)
+    probs = np.asarray(speech_probs, dtype=np.float64).reshape(-1)
+
+    thr = opts.threshold
+    neg = opts.neg_threshold if opts.neg_threshold is not None else max(thr - 0.15, 0.01)
+    per_ms = sampling_rate / 1000
+    min_speech = per_ms * opts.min_speech_duration_ms
+    pad = per_ms * opts.speech_pad_ms
+    max_speech = sampling_rate * opts.max_speech_duration_s - WINDOW - 2 * pad
+    min_silence = per_ms * opts.min_silence_duration_ms
+    min_silence_at_max = per_ms * 98
+
+    spans: List[dict] = []
+    start = None          # start sample of the open span (None: not triggered)
+    silence_at = 0        # sample where the current run of sub-neg windows began (0: none)
+    cut_end = cut_next = 0   # candidate cut (end of a >98 ms silence, restart point) for over-long spans
+
+    def close(end):
+        nonlocal start, silence_at, cut_end, cut_next
+        spans.append({"start": start, "end": end})
+        start, silence_at, cut_end, cut_next = None, 0, 0, 0
+
+    for i, p in enumerate(probs):
+        pos = WINDOW * i
+        if p >= thr and silence_at:
+            silence_at = 0
+            if cut_next < cut_end:
+                cut_next = pos
+        if p >= thr and start is None:
+            start = pos
+            continue
+        if start is not None and pos - start > max_speech:
+            if cut_end:
+                resume = cut_next if cut_next >= cut_end else None
+                close(cut_end)
+                start = resume
+            else:
+                close(pos)
+                continue
+        if p < neg and start is not None:
+            if not silence_at:
+                silence_at = pos
+            if pos - silence_at > min_silence_at_max:
+                cut_end = silence_at
+            if pos - silence_at < min_silence:
+                continue
+            if silence_at - start > min_speech:
+                close(silence_at)
+            else:
+                start, silence_at, cut_end, cut_next = None, 0, 0, 0
+    if start is not None and n_audio - start > min_speech:
+        spans.append({"start": start, "end": n_audio})
+
+    # padding: split the gap between neighbours when it is shorter than two pads
+    for k, span in enumerate(spans):
+        if k == 0:
+            span["start"] = int(max(0, span["start"] - pad))
+        if k + 1 < len(spans):
+            nxt = spans[k + 1]
+            gap = nxt["start"] - span["end"]
+            if gap < 2 * pad:
+                span["end"] += int(gap // 2)
+                nxt["start"] = int(max(0, nxt["start"] - gap // 2))
+            else:
+                span["end"] = int(min(n_audio, span["end"] + pad))
+                nxt["start"] = int(max(0, nxt["start"] - pad))
+        else:
+            span["end"] = int(min(n_audio, span["end"] + pad))
+    return spans
+
+
+def collect_chunks(audio: np.ndarray, chunks: List[dict], sampling_rate: int = 16000,
+                   max_duration: float = float("inf")) -> Tuple[List[np.ndarray], List[Dict[str, float]]]:
+    """Concatenates speech spans into chunks of at most `max_duration` seconds.
+    -> (audio per chunk, metadata per chunk {"offset": s on the silence-free axis, "duration": s, "segments": spans})"""
+    if not chunks:
+        return [np.array([], dtype=np.float32)], [{"offset": 0, "duration": 0, "segments": []}]
+    limit = max_duration * sampling_rate
+    out_audio, out_meta = [], []
+    pieces: List[np.ndarray] = []
+    members: List[dict] = []
+    length = 0       # samples in the open chunk
+    emitted = 0      # samples in the chunks already emitted
+
+    def flush():
+        nonlocal emitted
+        out_audio.append(np.concatenate(pieces) if pieces else np.array([], dtype=np.float32))
+        out_meta.append({"offset": emitted / sampling_rate, "duration": length / sampling_rate, "segments": members})
+        emitted += length
+
+    for span in chunks:
+        n = span["end"] - span["start"]
+        if length + n > limit:
+            flush()
+            # (reference behaviour, vad.py:212-227: the span that opens a new chunk is not listed in "segments")
+            pieces, members, length = [audio[span["start"]:span["end"]]], [], n
+        else:
+            pieces.append(audio[span["start"]:span["end"]])
+            members.append(span)
+            length += n
+    flush()
+    return out_audio, out_meta
+
+
+class SpeechTimestampsMap:
+    """Restores times measured on the concatenated-speech axis to the original recording."""
+
+    def __init__(self, chunks: List[dict], sampling_rate: int, time_precision: int = 2):
+        self.sampling_rate = sampling_rate
+        self.time_precision = time_precision
+        self.chunk_end_sample: List[int] = []
+        self.total_silence_before: List[float] = []
+        removed, prev_end = 0, 0
+        for c in chunks:
+            removed += c["start"] - prev_end
+            prev_end = c["end"]
+            self.chunk_end_sample.append(c["end"] - removed)
+            self.total_silence_before.append(removed / sampling_rate)
+
+    def get_chunk_index(self, time: float, is_end: bool = False) -> int:
+        sample = int(time * self.sampling_rate)
+        if is_end and sample in self.chunk_end_sample:
+            return self.chunk_end_sample.index(sample)
+        return min(bisect.bisect(self.chunk_end_sample, sample), len(self.chunk_end_sample) - 1)
+
+    def get_original_time(self, time: float, chunk_index: Optional[int] = None, is_end: bool = False) -> float:
+        if chunk_index is None:
+            chunk_index = self.get_chunk_index(time, is_end)
+        return round(self.total_silence_before[chunk_index] + time, self.time_precision)

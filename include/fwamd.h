@@ -215,7 +215,12 @@ int32_t fw_detect_language(fw_model* m, const fw_tensor* enc, int32_t B,
  * start_seq[n_start]: sot sequence; text tokens ragged via text_offsets[B+1];
  * num_frames[B] (mel frames, the reference passes segment_size).
  * Outputs: out_pairs int32 [B, max_pairs, 2] (text_idx, time_idx) with
- * out_n_pairs[B]; out_probs float ragged like text tokens (same offsets). */
+ * out_n_pairs[B]; out_probs float ragged like text tokens (same offsets).
+ * text_idx runs over n_text + 1 rows: row 0 is the <|notimestamps|> position
+ * (its attention times the first text token), row n_text the last text token;
+ * the reference looks the path's token jumps up with word boundaries 0..n_text
+ * (transcribe.py:1741-1745).  time_idx < num_frames / 2.
+ * max_pairs >= n_text + 1 + num_frames / 2. */
 int32_t fw_align(fw_model* m, const fw_tensor* enc, const int32_t* start_seq, int32_t n_start,
                  const int32_t* text_tokens, const int32_t* text_offsets, const int32_t* num_frames,
                  int32_t B, int32_t median_filter_width, int32_t max_pairs,

@@ -493,7 +493,10 @@ class OracleWhisper:
                 std = w.std(dim=-2, keepdim=True, unbiased=False)
                 w = (w - mean) / std
                 w = _median_filter(w.numpy(), median_filter_width)
-                m = w.mean(axis=0)[n0:-1]                                            # text rows only
+                # rows <|notimestamps|> .. last text token (n_text + 1 rows; the attention at a position times
+                # the token it predicts), openai-whisper timing.py `matrix[len(sot_sequence):-1]`; the reference
+                # indexes the token jumps up to n_text (transcribe.py:1741-1745), which needs exactly these rows
+                m = w.mean(axis=0)[n0 - 1:-1]
                 ti, fi = _dtw(-m.astype(np.float64))
                 out.append(AlignResult(list(zip(ti.tolist(), fi.tolist())), text_probs))
         return out

@@ -234,10 +234,11 @@ def test_align(setup):
         ri = np.array([i for i, _ in r.alignments])
         gj = gt[np.r_[True, np.diff(gi) > 0]]
         rj = rt[np.r_[True, np.diff(ri) > 0]]
-        assert len(gj) == len(rj) == len(text[b])
+        # n_text + 1 rows: the <|notimestamps|> position (predicting the first text token) .. the last text token
+        assert len(gj) == len(rj) == len(text[b]) + 1
         jd = int(np.abs(gj - rj).max())
         print(f"[{cfg.name}] align chunk {b}: token prob err {pe:.2e}, max jump-time diff {jd} frames, "
               f"path len {len(g.alignments)} vs {len(r.alignments)}")
         assert pe < 1e-3
-        assert gi[-1] == len(text[b]) - 1 and gt[-1] == num_frames[b] // 2 - 1
+        assert gi[0] == 0 and gi[-1] == len(text[b]) and gt[-1] == num_frames[b] // 2 - 1
         assert jd <= 2

@@ -98,8 +98,14 @@ def test_language_detection_and_errors(wm):
     with pytest.raises(RuntimeError):                   # > 30 s without clips and without VAD
         pipe.transcribe(audio, language="en", vad_filter=False)
     short = audio[:160000]
-    segs, _ = pipe.transcribe(short, language="en", beam_size=1, max_new_tokens=4)   # < 30 s: single clip
+    segs, _ = pipe.transcribe(short, language="en", beam_size=1, max_new_tokens=4, vad_filter=False)  # < 30 s: one clip
     assert len(list(segs)) >= 1
+    with pytest.raises(RuntimeError, match="Silero"):   # default vad_filter=True needs speech probabilities (row f-3)
+        pipe.transcribe(short, language="en", beam_size=1, max_new_tokens=4)
+    # ... which can be supplied: all-speech probabilities keep the whole clip
+    probs = np.full(len(short) // 512 + 1, 0.9, dtype=np.float32)
+    segs, info = pipe.transcribe(short, language="en", beam_size=1, max_new_tokens=4, vad_speech_probs=probs)
+    assert len(list(segs)) >= 1 and info.duration_after_vad == pytest.approx(10.0)
 
 
 def test_worker_replicas_share_weights(wm):

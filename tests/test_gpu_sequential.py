@@ -1,0 +1,110 @@
+"""The sequential path (WhisperModel.transcribe: seek loop, temperature fallback with random sampling, word
+timestamps — SURVEY.md section 8 rows a9 / a12 / f-2) end to end on the HIP engine, against the SAME host code
+running on the CPU oracle (oracle/oracle_backend.py).  Synthetic weights + the micro tokenizer."""
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import bench_audio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from faster_whisper_amd import get_config, synthetic_weights
+    from faster_whisper_amd.transcribe import FeatureExtractor, WhisperModel
+    from oracle import micro_tokenizer
+    from oracle.oracle_backend import OracleBackend
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=33)
+    tok = micro_tokenizer.build()
+    gpu = WhisperModel("synthetic:micro", device="cuda", compute_type="float16",
+                       files={"config": cfg, "weights": w, "tokenizer.json": tok.to_str().encode()},
+                       max_batch_size=4, max_beam_size=5)
+    cpu = WhisperModel.__new__(WhisperModel)
+    cpu.logger = logging.getLogger("oracle-host")
+    cpu.model = OracleBackend(cfg, w, emulate_fp16=True)
+    cpu.hf_tokenizer = tok
+    cpu.feature_extractor = FeatureExtractor(feature_size=cfg.n_mels, backend=cpu.model)
+    cpu.input_stride, cpu.time_precision, cpu.max_length = 2, 0.02, 448
+    cpu.num_samples_per_token = 320
+    cpu.frames_per_second, cpu.tokens_per_second = 100, 50
+    return cfg, gpu, cpu
+
+
+def _audio(seconds=52.0):
+    n = int(seconds * 16000)
+    parts = [bench_audio(480000, seed=40 + i) for i in range(n // 480000 + 1)]
+    return np.concatenate(parts)[:n]
+
+
+def _same_prefix(a, b):
+    n = 0
+    while n < min(len(a), len(b)) and a[n].tokens == b[n].tokens and a[n].seek == b[n].seek:
+        n += 1
+    return n
+
+
+def test_sequential_beam_with_word_timestamps(pair):
+    cfg, gpu, cpu = pair
+    audio = _audio()
+    kw = dict(language="en", beam_size=2, temperature=0.0, word_timestamps=True, max_new_tokens=20,
+              log_prob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+              suppress_tokens=[1, 2, 3])
+    got, info = gpu.transcribe(audio, **kw)
+    got = list(got)
+    ref = list(cpu.transcribe(audio, **kw)[0])
+    assert info.language == "en" and info.duration == pytest.approx(52.0)
+    assert len(got) >= 2 and [s.id for s in got] == list(range(1, len(got) + 1))
+    assert all(b.seek >= a.seek for a, b in zip(got, got[1:]))           # the seek loop only moves forward
+    for s in got:
+        assert s.words is not None and s.temperature == 0.0
+        for w in s.words:
+            assert w.end >= w.start >= 0.0 and 0.0 <= w.probability <= 1.0
+    n = _same_prefix(got, ref)
+    print(f"sequential beam: {n}/{len(ref)} leading segments identical to the oracle-driven host run")
+    assert n >= 1                      # the first window is free of accumulated low-margin divergence
+    for a, b in zip(got[:n], ref[:n]):
+        assert a.start == pytest.approx(b.start, abs=0.021) and a.end == pytest.approx(b.end, abs=0.021)
+        assert a.avg_logprob == pytest.approx(b.avg_logprob, abs=2e-3 * max(1.0, abs(b.avg_logprob)))
+        assert [w.word for w in a.words] == [w.word for w in b.words]
+        for wa, wb in zip(a.words, b.words):
+            assert wa.start == pytest.approx(wb.start, abs=0.045) and wa.end == pytest.approx(wb.end, abs=0.045)
+            assert wa.probability == pytest.approx(wb.probability, abs=2e-3)
+
+
+def test_temperature_fallback_uses_sampling(pair):
+    """log_prob_threshold = 0 can never be met: every window walks the whole ladder (beam search, then
+    best_of random samples per temperature) and returns the most probable attempt with the LAST temperature."""
+    cfg, gpu, cpu = pair
+    audio = _audio(31.0)
+    kw = dict(language="en", beam_size=2, best_of=3, temperature=[0.0, 0.5, 1.0], max_new_tokens=12,
+              log_prob_threshold=0.0, compression_ratio_threshold=None, no_speech_threshold=None,
+              condition_on_previous_text=False, suppress_tokens=[1, 2, 3])
+    got = list(gpu.transcribe(audio, **kw)[0])
+    ref = list(cpu.transcribe(audio, **kw)[0])
+    assert len(got) >= 1 and all(s.temperature == 1.0 for s in got)
+    # same Gumbel noise on both sides (seed 0): the first window's choice agrees unless a margin is tiny
+    n = _same_prefix(got, ref)
+    print(f"fallback ladder: {n}/{len(ref)} leading segments identical; avg_logprob {got[0].avg_logprob:.4f} "
+          f"vs {ref[0].avg_logprob:.4f}")
+    assert n >= 1 or abs(got[0].avg_logprob - ref[0].avg_logprob) < 0.05
+
+
+def test_sequential_multilingual_clips(pair):
+    cfg, gpu, cpu = pair
+    audio = _audio(40.0)
+    kw = dict(language=None, multilingual=True, beam_size=1, temperature=0.0, max_new_tokens=10,
+              clip_timestamps="2,18,20,36", without_timestamps=True, log_prob_threshold=None,
+              compression_ratio_threshold=None, no_speech_threshold=None)
+    got, info = gpu.transcribe(audio, **kw)
+    got = list(got)
+    ref, rinfo = cpu.transcribe(audio, **kw)
+    ref = list(ref)
+    assert info.language == rinfo.language
+    assert info.language_probability == pytest.approx(rinfo.language_probability, abs=2e-3)
+    # one window per clip, at the clip starts (a window whose text is empty yields no segment)
+    assert [s.seek for s in got] == [s.seek for s in ref] and all(s.seek in (200, 2000) for s in got)
+    assert _same_prefix(got, ref) == len(ref)
