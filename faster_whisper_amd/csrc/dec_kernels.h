@@ -22,7 +22,8 @@ struct GenDev {
   unsigned seed_lo, seed_hi;
 };
 
-void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, int rows, int d,
+void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
+                  int rows, int d,
                   const int* d_step, int pos_fixed, int P);
 int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
@@ -35,9 +36,13 @@ int launch_dec_gemm_i8(hipStream_t st, const int8_t* xq, const float* x_scale, c
                        bool out_f32);
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
-                      int pos_fixed, int P, int R_total);
+                      int pos_fixed, int P, int R_total, int frag);
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
-                       int kmul, half_t* out, int B, int H, const int* done, int kv_div);
+                       int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag);
+// frag = 1: `out` is a fragment-major [rows/16][d/32][64][8] buffer (input of launch_dec_gemm_frag)
+int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
+                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
+                         int N, int K, int act);
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
 void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
                            const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok);

@@ -17,9 +17,18 @@
 // ------------------------------------------------------------------------------------
 // K12: token + learned-position embedding  x[r] = E[tok[r]] + pos[p]
 // ------------------------------------------------------------------------------------
+// Fragment-major activations (decoder rows feeding the register-streaming skinny GEMM below): element
+// (row, k) of a [R][K] matrix lives at ((row/16 * K/32 + k/32) * 64 + lane) * 8 + k%8 with
+// lane = 16 * ((k/8) % 4) + row % 16 — i.e. the 16 bytes lane l needs for MFMA k-step ks of row tile rt are
+// at ((rt*KS + ks)*64 + l)*16 B: one wave load = one contiguous 1 KB run.
+__device__ __forceinline__ size_t frag_off(int row, int k, int KS) {
+  return ((size_t)((row >> 4) * KS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (row & 15)) * 8 + (k & 7);
+}
+
 __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __restrict__ emb,
-                                 const half_t* __restrict__ pos_emb, half_t* __restrict__ x, int d,
-                                 const int* __restrict__ d_step, int pos_fixed, int P) {
+                                 const half_t* __restrict__ pos_emb, half_t* __restrict__ x,
+                                 half_t* __restrict__ xfrag, int d, const int* __restrict__ d_step, int pos_fixed,
+                                 int P) {
   const int r = blockIdx.x;
   const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + *d_step;
   const half2_t* e = reinterpret_cast<const half2_t*>(emb + (size_t)tok[r] * d);
@@ -31,6 +40,7 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
     o[0] = (half_t)((float)a[0] + (float)b[0]);
     o[1] = (half_t)((float)a[1] + (float)b[1]);
     xo[i] = o;
+    if (xfrag) *reinterpret_cast<half2_t*>(xfrag + frag_off(r, 2 * i, d >> 5)) = o;
   }
 }
 
@@ -390,6 +400,107 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
 }
 
 // ------------------------------------------------------------------------------------
+// Skinny GEMM, register-streaming form over FRAGMENT-MAJOR operands (frag_off above).
+//
+// Both the weights (permuted once at pack time) and the activations (written in this order by their
+// producers: embed, the attention kernels, this kernel's own epilogue) are stored so that the 16 bytes a lane
+// feeds to v_mfma_f32_16x16x32_f16 for k-step ks are at (tile*KS + ks)*1 KB + lane*16 B.  Every wave load is
+// one contiguous 1 KB run, operands go straight from L2/HBM to VGPRs: no LDS staging, no DMA ring, no
+// barriers in the K loop, so a workgroup holds no LDS while it waits on memory (the LDS-staged form above is
+// latency-bound single stream AND LDS-residency-bound with several batches in flight).
+//   * one workgroup = one 16-column tile x one 16-row tile; its WAVES waves split K and issue ALL their
+//     loads at once (10 k-steps = 20 x 16 B per lane): one memory latency per launch for K <= 1280;
+//   * grid (N/16, row tiles): the row tiles of a column tile land on the same XCD (N/16 is a multiple of 8),
+//     so a weight tile is fetched from HBM once and re-read from that XCD's L2;
+//   * fixed-order reduction of the WAVES partial tiles through 4 KB of LDS, epilogue by wave 0.
+// ------------------------------------------------------------------------------------
+template <int WAVES, bool LNF>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
+    const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
+    const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
+    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
+  __shared__ float red[WAVES][64][4];
+  __shared__ float red_s[WAVES][16][2];
+  constexpr int CH = 10;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int ct = blockIdx.x, rt = blockIdx.y;
+  const int KS = K >> 5;
+  const int per = (KS + WAVES - 1) / WAVES;
+  const int ks0 = wave * per;
+  int nks = KS - ks0;
+  if (nks > per) nks = per;
+  floatx4 acc = {0, 0, 0, 0};
+  float rs = 0.f, rq = 0.f;
+  if (nks > 0) {
+    const half8_t* wp = reinterpret_cast<const half8_t*>(Wf) + ((size_t)ct * KS + ks0) * 64 + lane;
+    const half8_t* xp = reinterpret_cast<const half8_t*>(xf) + ((size_t)rt * KS + ks0) * 64 + lane;
+    for (int c = 0; c < nks; c += CH) {
+      half8_t wv[CH], xv[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int jj = (c + j < nks) ? c + j : nks - 1;   // clamped: a tail slot re-reads the last step, unused
+        wv[j] = wp[(size_t)jj * 64];
+        xv[j] = xp[(size_t)jj * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if (c + j < nks) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[j], xv[j], acc, 0, 0, 0);
+          if (LNF) {
+            const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h2 = {xv[j][2 * e], xv[j][2 * e + 1]};
+              rs = __builtin_amdgcn_fdot2(h2, one2, rs, false);
+              rq = __builtin_amdgcn_fdot2(h2, h2, rq, false);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (LNF) {   // row i's statistics: the 4 k-octet lanes of the row, then the waves
+    rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
+    rq += __shfl_xor(rq, 16, 64); rq += __shfl_xor(rq, 32, 64);
+    if (g == 0) { red_s[wave][i][0] = rs; red_s[wave][i][1] = rq; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][lane][e] = acc[e];
+  __syncthreads();
+  if (wave != 0) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += red[w][lane][e];
+  const int row = rt * 16 + i;
+  if (row >= R) return;
+  float mu = 0.f, rstd = 1.f;
+  if (LNF) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { sa += red_s[w][i][0]; sb += red_s[w][i][1]; }
+    mu = sa / (float)K;
+    rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
+  }
+  const int n = ct * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
+  half4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float tv = v[e];
+    if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
+    else if (bias) tv += (float)bias[n + e];
+    if (act == 1) tv = gelu_erf(tv);
+    if (res) tv += (float)res[(size_t)row * ldr + n + e];
+    o[e] = (half_t)tv;
+  }
+  if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
+  if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
+}
+
+// ------------------------------------------------------------------------------------
 // K13: decoder self-attention for one (row, head), KV cache with slot indirection.
 // cache layout [slot][H][n_ctx][64].  The new K/V (position pos) are written to the row's
 // own slot; older positions are read from kvidx[row][p] (slot inside the chunk).
@@ -400,7 +511,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
                                                            half_t* __restrict__ vc, int n_ctx, int H,
                                                            const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
                                                            half_t* __restrict__ out, const int* __restrict__ d_step,
-                                                           int pos_fixed, int P, int R_total) {
+                                                           int pos_fixed, int P, int R_total, int frag) {
   __shared__ float sq[64];
   __shared__ float sp[448];
   __shared__ int ssrc[448];
@@ -474,7 +585,8 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (half_t)((acc[e] + e_new * (float)vn[e]) * inv);
-    *reinterpret_cast<half8_t*>(out + (size_t)r * d + h * 64 + cc * 8) = o;
+    half_t* dst = frag ? out + frag_off(r, h * 64 + cc * 8, d >> 5) : out + (size_t)r * d + h * 64 + cc * 8;
+    *reinterpret_cast<half8_t*>(dst) = o;
   }
 }
 
@@ -498,7 +610,7 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
                                                              const half_t* __restrict__ ck,
                                                              const half_t* __restrict__ cvt, int T, int kvp,
                                                              int kmul, half_t* __restrict__ out,
-                                                             const int* __restrict__ done, int kv_div) {
+                                                             const int* __restrict__ done, int kv_div, int frag) {
   __shared__ float sm[CA_WAVES][16], sl[CA_WAVES][16];
   __shared__ float so[CA_WAVES][16][65];
   const int h = blockIdx.x, c = blockIdx.y;
@@ -608,7 +720,9 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
       Lsum += sl[w][qq] * f;
       O += so[w][qq][dh] * f;
     }
-    out[(size_t)(c * kmul + qq) * d + h * 64 + dh] = (half_t)(O / Lsum);
+    const int orow = c * kmul + qq;
+    half_t* dst = frag ? out + frag_off(orow, h * 64 + dh, d >> 5) : out + (size_t)orow * d + h * 64 + dh;
+    *dst = (half_t)(O / Lsum);
   }
 }
 
@@ -1031,9 +1145,9 @@ __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __re
 
 namespace fwd {
 
-void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, int rows, int d,
-                  const int* d_step, int pos_fixed, int P) {
-  dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, d, d_step, pos_fixed, P);
+void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
+                  int rows, int d, const int* d_step, int pos_fixed, int P) {
+  dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, xfrag, d, d_step, pos_fixed, P);
 }
 
 template <int MT, int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool F32>
@@ -1211,21 +1325,39 @@ int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, c
 #undef ARGS
 }
 
+// Register-streaming skinny GEMM over fragment-major x / W (see dec_gemm_frag_kernel).  out (row-major) and
+// out_frag (fragment-major, for the next GEMM) are both optional; res is row-major.
+int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
+                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
+                         int N, int K, int act) {
+  if (K % 32 != 0 || N % 16 != 0 || R < 1 || R > 80) return -1;
+  const dim3 grid(N / 16, (R + 15) / 16);
+  const bool lnf = s1 != nullptr;
+  if (K >= 2560) {
+    if (lnf) dec_gemm_frag_kernel<8, true><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    else dec_gemm_frag_kernel<8, false><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  } else {
+    if (lnf) dec_gemm_frag_kernel<4, true><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    else dec_gemm_frag_kernel<4, false><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  }
+  return 0;
+}
+
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
-                      int pos_fixed, int P, int R_total) {
+                      int pos_fixed, int P, int R_total, int frag) {
   dec_self_attn_kernel<<<dim3(H, rows), 64, 0, st>>>(qkv, d, kc, vc, n_ctx, H, kvidx2, Kbeam, kmul, out, d_step,
-                                                     pos_fixed, P, R_total);
+                                                     pos_fixed, P, R_total, frag);
 }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
-                       int kmul, half_t* out, int B, int H, const int* done, int kv_div) {
+                       int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag) {
   // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup; FWAMD_CA_WAVES=4 halves that
   static const int waves = [] { const char* e = getenv("FWAMD_CA_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
   if (waves == 4)
-    dec_cross_attn_kernel<4><<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div);
+    dec_cross_attn_kernel<4><<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
   else
-    dec_cross_attn_kernel<8><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div);
+    dec_cross_attn_kernel<8><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {

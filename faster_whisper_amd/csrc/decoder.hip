@@ -47,6 +47,7 @@ struct GenWorkspace {
   float* no_speech = nullptr;
   uint8_t* sup_mask = nullptr;
   int* zero_done = nullptr;              // [B] zeros (kernels that take a `done` pointer outside generate)
+  half_t *x_frag = nullptr, *att_frag = nullptr, *ffn_frag = nullptr;   // fragment-major GEMM inputs (dec_frag)
   int8_t* xq = nullptr;                  // int8_float16: quantised linear input [R][4d]
   float* xs = nullptr;                   //               per-row de-quantisation scale [R]
   // graph cache for the decode step
@@ -99,6 +100,13 @@ int gen_workspace_create(Model* m) {
     A(g->xq, Rg * 4 * d);
     A(g->xs, Rg);
   }
+  if (m->dec_frag) {
+    const size_t R16 = (Rg + 15) / 16 * 16;   // whole 16-row tiles
+    A(g->x_frag, R16 * d); A(g->att_frag, R16 * d); A(g->ffn_frag, R16 * 4 * d);
+    FW_HIP(hipMemset(g->x_frag, 0, R16 * d * sizeof(half_t)));
+    FW_HIP(hipMemset(g->att_frag, 0, R16 * d * sizeof(half_t)));
+    FW_HIP(hipMemset(g->ffn_frag, 0, R16 * 4 * d * sizeof(half_t)));
+  }
 #undef A
   // the padded keys (>= T) are never written: K garbage is masked, V^T must be 0 (0 * NaN)
   FW_HIP(hipMemset(g->ck, 0, L * B * d * g->kvp * sizeof(half_t)));
@@ -117,7 +125,7 @@ void gen_workspace_free(Model* m) {
   void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->xn, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_mask,
-                  g->zero_done, g->xq, g->xs};
+                  g->zero_done, g->xq, g->xs, g->x_frag, g->att_frag, g->ffn_frag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -192,7 +200,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   (void)wbytes_layer;
   {
     ProfScope ps(m, PF_DEC_MISC, 0, 0);
-    fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, rows, d, g->d_step, s.pos_fixed, s.P);
+    fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, m->dec_frag ? g->x_frag : nullptr, rows, d, g->d_step,
+                      s.pos_fixed, s.P);
   }
   // one decoder linear: x[rows][K] -> out[rows][N]; LayerNorm-folded when L.s1 is set; in-place residual
   static const bool use_lds_gemm = !(getenv("FWAMD_REG_GEMM") && getenv("FWAMD_REG_GEMM")[0] == '1');
@@ -203,6 +212,14 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K);
     return fwd::launch_dec_gemm_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K, act,
                                    false);
+  };
+  // fragment-major flow (m->dec_frag, fp16): xin is the fragment-major copy of the input; the residual stream is
+  // kept row-major too (logits GEMM, residual adds), the FFN hidden only fragment-major
+  const bool frag = m->dec_frag;
+  auto lin_f = [&](const half_t* xin_frag, const LinearW& L, const half_t* res, half_t* outp, half_t* outp_frag,
+                   int act) -> int {
+    return fwd::launch_dec_gemm_frag(st, xin_frag, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, outp_frag, rows, L.N,
+                                     L.K, act);
   };
   auto lin = [&](const half_t* xin, const LNW* ln, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
     if (i8) return lin_q(xin, ln, L, res, outp, act);
@@ -218,17 +235,23 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * g->kvp;
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
-      DG(lin(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
+      if (frag) DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
+      else DG(lin(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
     }
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0);
-      fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, H, g->kvidx2, gp.K, s.kmul, g->att, rows, g->d_step,
-                            s.pos_fixed, s.P, gp.R);
+      fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, H, g->kvidx2, gp.K, s.kmul, frag ? g->att_frag : g->att, rows,
+                            g->d_step, s.pos_fixed, s.P, gp.R, frag ? 1 : 0);
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
-      DG(lin(g->att, nullptr, L.out, g->x, g->x, 0));
-      DG(lin(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
+      if (frag) {
+        DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0));
+        DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0));
+      } else {
+        DG(lin(g->att, nullptr, L.out, g->x, g->x, 0));
+        DG(lin(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
+      }
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0);
@@ -238,19 +261,23 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * s.B * (double)T * d);
-      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, g->kvp, s.kmul, g->att, s.B, H, s.done, s.kv_div);
+      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, g->kvp, s.kmul, frag ? g->att_frag : g->att, s.B, H, s.done,
+                             s.kv_div, frag ? 1 : 0);
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d);
-      DG(lin(g->att, nullptr, L.cout, g->x, g->x, 0));
+      if (frag) DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0));
+      else DG(lin(g->att, nullptr, L.cout, g->x, g->x, 0));
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      DG(lin(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
+      if (frag) DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
+      else DG(lin(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      DG(lin(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
+      if (frag) DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0));
+      else DG(lin(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
     }
   }
   if (s.need_logits || s.beam_tail) {

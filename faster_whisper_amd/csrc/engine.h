@@ -31,6 +31,8 @@ void set_error(const char* fmt, ...);
 
 // ---- weight blob (what travels over RCCL at load time) --------------------------------
 #define FW_BLOB_MAGIC "FWAMDBL1"
+// default decoder GEMM form when FWAMD_DEC_GEMM is unset (0: LDS-staged, 1: fragment-major register streaming)
+#define FWAMD_DEC_FRAG_DEFAULT 1
 struct BlobHeader {
   char magic[8];
   int32_t version;
@@ -95,6 +97,7 @@ struct GenWorkspace;  // decoder-side buffers (decoder.hip)
 struct Model {
   fw_config cfg{};
   int compute_type = 0;
+  bool dec_frag = false;   // decoder linears + their inputs are stored MFMA-fragment-major (dec_gemm_frag_kernel)
   int device = 0;
   int max_batch = 0, max_beam = 0;
   hipStream_t stream = nullptr;

@@ -171,6 +171,15 @@ static int check_config(const fw_config* c) {
 }
 
 // Build the device blob image on the host. All tensors fp16, final kernel layouts.
+// decoder skinny-GEMM form, decided when the weights are packed (the blob carries the flag, so worker replicas
+// and other ranks that receive the blob agree): fragment-major register-streaming kernel unless FWAMD_DEC_GEMM=lds
+static bool dec_frag_enabled() {
+  const char* e = getenv("FWAMD_DEC_GEMM");
+  if (e && e[0] == 'l') return false;
+  if (e && e[0] == 'f') return true;
+  return FWAMD_DEC_FRAG_DEFAULT;
+}
+
 static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compute_type,
                      std::vector<uint8_t>& blob) {
   const int d = cfg->d_model, nm = cfg->n_mels;
@@ -340,6 +349,38 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   }
 #undef TRY
 
+  // Fragment-major decoder linears (dec_kernels.hip: dec_gemm_frag_kernel): W[n][k] moves to
+  // ((n/16 * K/32 + k/32) * 64 + 16*((k/8)%4) + n%16) * 8 + k%8, so that the 16 bytes lane l feeds to the MFMA
+  // for k-step ks of column tile nt sit at ((nt*KS + ks)*64 + l)*16 B.  fp16 mode only; the big "many rows"
+  // GEMM (cross.kv) and the logits projection keep [N][K].
+  const bool frag = dec_frag_enabled() && !i8;
+  if (frag) {
+    for (PackItem& it : items) {
+      const std::string& nm = it.name;
+      if (nm.compare(0, 4, "dec.") != 0 || it.ndim != 2 || it.dtype != 1) continue;
+      auto ends = [&](const char* suf) {
+        const size_t n = strlen(suf);
+        return nm.size() >= n && nm.compare(nm.size() - n, n, suf) == 0;
+      };
+      if (!(ends("self.qkv.wf") || ends("self.out.w") || ends("cross.q.wf") || ends("cross.out.w") ||
+            ends("ffn1.wf") || ends("ffn2.w")))
+        continue;
+      const int64_t N = it.dims[0], K = it.dims[1];
+      if (N % 16 || K % 32) {
+        set_error("fragment-major packing needs N %% 16 == 0 and K %% 32 == 0 (%s is %lld x %lld)", nm.c_str(),
+                  (long long)N, (long long)K);
+        return FW_EINVAL;
+      }
+      std::vector<uint16_t> src;
+      src.swap(it.data);
+      it.data.resize(src.size());
+      const int64_t KS = K / 32;
+      for (int64_t n = 0; n < N; ++n)
+        for (int64_t k = 0; k < K; ++k)
+          it.data[(((n >> 4) * KS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7)] = src[n * K + k];
+    }
+  }
+
   const int64_t hdr = (int64_t)sizeof(BlobHeader) + (int64_t)items.size() * sizeof(BlobEntry);
   int64_t off = (hdr + 255) / 256 * 256;
   std::vector<BlobEntry> entries(items.size());
@@ -362,6 +403,7 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   h.n_tensors = (int32_t)items.size();
   h.total_bytes = off;
   h.compute_type = compute_type;
+  h.reserved = frag ? 1 : 0;   // bit 0: decoder linears are fragment-major
   h.cfg = *cfg;
   memcpy(blob.data(), &h, sizeof(h));
   memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
@@ -595,6 +637,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   Model* m = &fm->impl;
   m->cfg = h.cfg;
   m->compute_type = h.compute_type;
+  m->dec_frag = (h.reserved & 1) != 0;
   m->device = device;
   m->max_batch = max_batch;
   m->max_beam = max_beam;

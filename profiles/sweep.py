@@ -35,7 +35,8 @@ def main():
     from faster_whisper_amd import Whisper, get_config, pack_blob, synthetic_weights
 
     cfg = get_config(args.model)
-    cache = f"/tmp/fwamd_blob_{args.model}_{args.compute_type}.npy"
+    # the decoder weight layout is decided at pack time (FWAMD_DEC_GEMM), so it is part of the cache key
+    cache = f"/tmp/fwamd_blob_{args.model}_{args.compute_type}_{os.environ.get('FWAMD_DEC_GEMM', 'default')}.npy"
     t0 = time.time()
     if os.path.exists(cache):
         blob = np.load(cache, mmap_mode="r")
