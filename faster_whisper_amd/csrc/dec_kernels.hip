@@ -414,90 +414,128 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restr
 //     so a weight tile is fetched from HBM once and re-read from that XCD's L2;
 //   * fixed-order reduction of the WAVES partial tiles through 4 KB of LDS, epilogue by wave 0.
 // ------------------------------------------------------------------------------------
-template <int WAVES, bool LNF>
+template <int WAVES, bool LNF, int RT, int NT>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
     half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
-  __shared__ float red[WAVES][64][4];
-  __shared__ float red_s[WAVES][16][2];
-  constexpr int CH = 10;
+  // RT x NT tiles of 16 x 16 per workgroup (1 x 1 by default; larger tiles re-use the x / W fragments in
+  // registers and cut the L2 re-reads at the price of fewer workgroups — experiment knobs, see the launcher)
+  __shared__ float red[WAVES][RT * NT][64][4];
+  __shared__ float red_s[WAVES][RT][16][2];
+  constexpr int CH = 20 / (RT + NT);   // k-steps in flight per wave: (RT + NT) * CH * 16 B per lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int ct = blockIdx.x, rt = blockIdx.y;
+  const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
+  const int n_rt = (R + 15) >> 4;
   const int KS = K >> 5;
   const int per = (KS + WAVES - 1) / WAVES;
   const int ks0 = wave * per;
   int nks = KS - ks0;
   if (nks > per) nks = per;
-  floatx4 acc = {0, 0, 0, 0};
-  float rs = 0.f, rq = 0.f;
+  floatx4 acc[RT][NT];
+  float rs[RT], rq[RT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a) {
+    rs[a] = 0.f; rq[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = floatx4{0, 0, 0, 0};
+  }
   if (nks > 0) {
-    const half8_t* wp = reinterpret_cast<const half8_t*>(Wf) + ((size_t)ct * KS + ks0) * 64 + lane;
-    const half8_t* xp = reinterpret_cast<const half8_t*>(xf) + ((size_t)rt * KS + ks0) * 64 + lane;
+    const half8_t* wp[NT];
+    const half8_t* xp[RT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+      wp[b] = reinterpret_cast<const half8_t*>(Wf) + ((size_t)(ct0 + b) * KS + ks0) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      int rt = rt0 + a;
+      if (rt > n_rt - 1) rt = n_rt - 1;   // a missing row tile re-reads the last one; its result is dropped
+      xp[a] = reinterpret_cast<const half8_t*>(xf) + ((size_t)rt * KS + ks0) * 64 + lane;
+    }
     for (int c = 0; c < nks; c += CH) {
-      half8_t wv[CH], xv[CH];
+      half8_t wv[NT][CH], xv[RT][CH];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const int jj = (c + j < nks) ? c + j : nks - 1;   // clamped: a tail slot re-reads the last step, unused
-        wv[j] = wp[(size_t)jj * 64];
-        xv[j] = xp[(size_t)jj * 64];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) wv[b][j] = wp[b][(size_t)jj * 64];
+#pragma unroll
+        for (int a = 0; a < RT; ++a) xv[a][j] = xp[a][(size_t)jj * 64];
       }
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         if (c + j < nks) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[j], xv[j], acc, 0, 0, 0);
-          if (LNF) {
-            const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const half2_t h2 = {xv[j][2 * e], xv[j][2 * e + 1]};
-              rs = __builtin_amdgcn_fdot2(h2, one2, rs, false);
-              rq = __builtin_amdgcn_fdot2(h2, h2, rq, false);
+          for (int a = 0; a < RT; ++a) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[b][j], xv[a][j], acc[a][b], 0, 0, 0);
+            if (LNF) {
+              const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const half2_t h2 = {xv[a][j][2 * e], xv[a][j][2 * e + 1]};
+                rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
+                rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
+              }
             }
           }
         }
       }
     }
   }
-  if (LNF) {   // row i's statistics: the 4 k-octet lanes of the row, then the waves
-    rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
-    rq += __shfl_xor(rq, 16, 64); rq += __shfl_xor(rq, 32, 64);
-    if (g == 0) { red_s[wave][i][0] = rs; red_s[wave][i][1] = rq; }
-  }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[wave][lane][e] = acc[e];
+  for (int a = 0; a < RT; ++a) {
+    if (LNF) {   // row i's statistics: the 4 k-octet lanes of the row, then the waves
+      float sa = rs[a], sb = rq[a];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      if (g == 0) { red_s[wave][a][i][0] = sa; red_s[wave][a][i][1] = sb; }
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][a * NT + b][lane][e] = acc[a][b][e];
+  }
   __syncthreads();
-  if (wave != 0) return;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  // fixed-order reduction + epilogue, tile t by wave t % WAVES
 #pragma unroll
-  for (int w = 0; w < WAVES; ++w)
+  for (int a = 0; a < RT; ++a) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += red[w][lane][e];
-  const int row = rt * 16 + i;
-  if (row >= R) return;
-  float mu = 0.f, rstd = 1.f;
-  if (LNF) {
-    float sa = 0.f, sb = 0.f;
+    for (int b = 0; b < NT; ++b) {
+      if ((a * NT + b) % WAVES != wave) continue;
+      const int row = (rt0 + a) * 16 + i;
+      if (row >= R) continue;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) { sa += red_s[w][i][0]; sb += red_s[w][i][1]; }
-    mu = sa / (float)K;
-    rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
+      for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += red[w][a * NT + b][lane][e];
+      float mu = 0.f, rstd = 1.f;
+      if (LNF) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { sa += red_s[w][a][i][0]; sb += red_s[w][a][i][1]; }
+        mu = sa / (float)K;
+        rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
+      }
+      const int n = (ct0 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
+      half4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float tv = v[e];
+        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
+        else if (bias) tv += (float)bias[n + e];
+        if (act == 1) tv = gelu_erf(tv);
+        if (res) tv += (float)res[(size_t)row * ldr + n + e];
+        o[e] = (half_t)tv;
+      }
+      if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
+      if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
+    }
   }
-  const int n = ct * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
-  half4_t o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float tv = v[e];
-    if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-    else if (bias) tv += (float)bias[n + e];
-    if (act == 1) tv = gelu_erf(tv);
-    if (res) tv += (float)res[(size_t)row * ldr + n + e];
-    o[e] = (half_t)tv;
-  }
-  if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
-  if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1325,21 +1363,39 @@ int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, c
 #undef ARGS
 }
 
+template <bool LNF, int RT, int NT>
+static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
+                    const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N,
+                    int K, int act) {
+  const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
+  if (waves == 8)
+    dec_gemm_frag_kernel<8, LNF, RT, NT><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N,
+                                                               K, act);
+  else
+    dec_gemm_frag_kernel<4, LNF, RT, NT><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N,
+                                                               K, act);
+}
+
 // Register-streaming skinny GEMM over fragment-major x / W (see dec_gemm_frag_kernel).  out (row-major) and
 // out_frag (fragment-major, for the next GEMM) are both optional; res is row-major.
+// Knobs: FWAMD_FRAG_RT / FWAMD_FRAG_NT = 1 | 2 (row / column tiles per workgroup), FWAMD_FRAG_WAVES = 4 | 8.
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act) {
-  if (K % 32 != 0 || N % 16 != 0 || R < 1 || R > 80) return -1;
-  const dim3 grid(N / 16, (R + 15) / 16);
+  if (K % 32 != 0 || N % 32 != 0 || R < 1 || R > 80) return -1;
+  // default 2 x 2 tiles (32 rows x 32 columns per workgroup): measured 1255x single stream / 2102x with 8 batches
+  // in flight, against 1278x / 1957x for 1 x 1 (profiles/r01_sweep_dec_gemm_frag_tiles.jsonl)
+  static const int env_rt = [] { const char* e = getenv("FWAMD_FRAG_RT"); return (e && e[0] == '1') ? 1 : 2; }();
+  static const int env_nt = [] { const char* e = getenv("FWAMD_FRAG_NT"); return (e && e[0] == '1') ? 1 : 2; }();
+  static const int env_w = [] { const char* e = getenv("FWAMD_FRAG_WAVES"); return e ? atoi(e) : 0; }();
+  const int waves = (env_w == 4 || env_w == 8) ? env_w : (K >= 2560 ? 8 : 4);
   const bool lnf = s1 != nullptr;
-  if (K >= 2560) {
-    if (lnf) dec_gemm_frag_kernel<8, true><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    else dec_gemm_frag_kernel<8, false><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-  } else {
-    if (lnf) dec_gemm_frag_kernel<4, true><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    else dec_gemm_frag_kernel<4, false><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-  }
+#define FG(L, A, B) frag_go<L, A, B>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
+  if (env_rt == 2 && env_nt == 2) { if (lnf) FG(true, 2, 2); else FG(false, 2, 2); }
+  else if (env_rt == 2) { if (lnf) FG(true, 2, 1); else FG(false, 2, 1); }
+  else if (env_nt == 2) { if (lnf) FG(true, 1, 2); else FG(false, 1, 2); }
+  else { if (lnf) FG(true, 1, 1); else FG(false, 1, 1); }
+#undef FG
   return 0;
 }
 
