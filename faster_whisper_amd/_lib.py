@@ -52,6 +52,14 @@ class FwGenOpts(C.Structure):
     ]
 
 
+class FwVadWeights(C.Structure):
+    _fields_ = [
+        ("stft_basis", C.c_void_p), ("conv_w", C.c_void_p * 4), ("conv_b", C.c_void_p * 4),
+        ("lstm_w", C.c_void_p), ("lstm_r", C.c_void_p), ("lstm_b", C.c_void_p), ("dec_w", C.c_void_p),
+        ("dec_b", C.c_float),
+    ]
+
+
 # every symbol include/fwamd.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [
     "fw_last_error", "fw_abi_version", "fw_device_count",
@@ -64,6 +72,7 @@ SYMBOLS = [
     "fw_prof_enable", "fw_prof_reset", "fw_prof_count", "fw_prof_name", "fw_prof_get", "fw_synchronize",
     "fw_dev_alloc", "fw_dev_free", "fw_dev_upload",
     "fw_test_gemm", "fw_test_layernorm", "fw_test_attention",
+    "fw_vad_create", "fw_vad_forward", "fw_vad_free",
 ]
 
 _lib = None
@@ -126,6 +135,10 @@ def load():
     lib.fw_test_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.fw_test_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.fw_test_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.fw_vad_create.argtypes = [C.POINTER(FwVadWeights), C.POINTER(vp)]
+    lib.fw_vad_forward.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.fw_vad_free.argtypes = [vp]
+    lib.fw_vad_free.restype = None
     _lib = lib
     return lib
 

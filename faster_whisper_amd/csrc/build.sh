@@ -12,6 +12,11 @@ for f in logmel gemm rowops attn_enc engine decoder dec_kernels; do
     pids+=($!)
   fi
 done
+# host-only C++ (Silero VAD network): g++, with AVX2 / AVX-512 clones selected at run time (target_clones)
+if [ ! -f build/vad_host.o ] || [ vad_host.cpp -nt build/vad_host.o ] || [ ../../include/fwamd.h -nt build/vad_host.o ]; then
+  g++ -O3 -std=c++17 -fPIC -Wall -c vad_host.cpp -o build/vad_host.o &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread build/*.o -o $OUT
 echo "built $(realpath $OUT)"

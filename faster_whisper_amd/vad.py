@@ -43,9 +43,7 @@ def get_speech_timestamps(audio: np.ndarray, vad_options: Optional[VadOptions] =
     n_audio = len(audio)
     if speech_probs is None:
         if vad_model is None:
-            raise RuntimeError("the Silero VAD network is not built in this tier (SURVEY.md section 8f-3): pass "
-                               "speech_probs= (one probability per 512-sample window) or vad_model=, or give "
-                               "clip_timestamps to transcribe()")
+            vad_model = get_vad_model()
         # the reference always appends 1..512 zero samples (a whole extra window when already aligned)
         padded = np.pad(audio, (0, WINDOW - n_audio % WINDOW))
         speech_probs = vad_model(padded)
@@ -177,3 +175,114 @@ class SpeechTimestampsMap:
         if chunk_index is None:
             chunk_index = self.get_chunk_index(time, is_end)
         return round(self.total_silence_before[chunk_index] + time, self.time_precision)
+
+
+# ---- the Silero VAD v6 network (row f-3): native host implementation behind the C ABI ---------------------
+_VAD_MODEL = None
+ONNX_ENV = "FWAMD_SILERO_VAD_ONNX"
+
+
+def find_vad_onnx() -> Optional[str]:
+    """Where the network's weights come from: the ONNX asset the reference ships
+    (`faster_whisper/assets/silero_vad_v6.onnx`, vad.py:288-292).  This repository does not redistribute it:
+    $FWAMD_SILERO_VAD_ONNX, else the assets directory of an installed `faster_whisper` package."""
+    import importlib.util
+    import os
+    path = os.environ.get(ONNX_ENV)
+    if path:
+        return path if os.path.isfile(path) else None
+    try:
+        spec = importlib.util.find_spec("faster_whisper")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "assets", "silero_vad_v6.onnx")
+        if os.path.isfile(cand):
+            return cand
+    return None
+
+
+def get_vad_model():
+    """Cached SileroVADModel (vad.py:288-292); fails loudly when the weights cannot be found."""
+    global _VAD_MODEL
+    if _VAD_MODEL is None:
+        path = find_vad_onnx()
+        if path is None:
+            raise RuntimeError(
+                "Silero VAD weights not found: set FWAMD_SILERO_VAD_ONNX to the reference's "
+                "faster_whisper/assets/silero_vad_v6.onnx (or install faster_whisper), or pass speech_probs= / "
+                "vad_model= / clip_timestamps")
+        _VAD_MODEL = SileroVADModel(path)
+    return _VAD_MODEL
+
+
+class SileroVADModel:
+    """Same call contract as the reference's SileroVADModel (vad.py:295-351): `model(padded_audio)` -> one speech
+    probability per 512-sample window.  The network runs in libfwamd.so's host C++ implementation
+    (csrc/vad.hip, `fw_vad_*`); the ONNX file is only the container of the weights (onnx_lite.py)."""
+
+    SHAPES = {"encoder.feature_extractor.forward_basis_buffer": (258, 1, 256),
+              "encoder.conv_layers.0.weight": (128, 129, 3), "encoder.conv_layers.1.weight": (64, 128, 3),
+              "encoder.conv_layers.2.weight": (64, 64, 3), "encoder.conv_layers.3.weight": (128, 64, 3),
+              "decoder.conv1d.weight": (1, 128, 1)}
+
+    def __init__(self, path: Optional[str] = None, weights: Optional[Dict[str, np.ndarray]] = None,
+                 n_threads: int = 0):
+        import ctypes as C
+        from . import _lib, onnx_lite
+        if weights is None:
+            _, weights, _, _ = onnx_lite.load(path)
+        for name, shape in self.SHAPES.items():
+            if name not in weights or tuple(weights[name].shape) != shape:
+                raise ValueError(f"not a Silero VAD v6 model: initializer '{name}' missing or not {shape}")
+        mats = [v for v in weights.values() if tuple(v.shape) == (1, 512, 128)]
+        bias = [v for v in weights.values() if tuple(v.shape) == (1, 1024)]
+        if len(mats) != 2 or len(bias) != 1:
+            raise ValueError("not a Silero VAD v6 model: expected LSTM W, R [1,512,128] and B [1,1024]")
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)   # noqa: E731
+        self._keep = dict(
+            basis=f32(weights["encoder.feature_extractor.forward_basis_buffer"]),
+            cw=[f32(weights[f"encoder.conv_layers.{i}.weight"]) for i in range(4)],
+            cb=[f32(weights[f"encoder.conv_layers.{i}.bias"]) for i in range(4)],
+            lw=f32(mats[0]), lr=f32(mats[1]), lb=f32(bias[0]), dw=f32(weights["decoder.conv1d.weight"]))
+        k = self._keep
+        w = _lib.FwVadWeights()
+        w.stft_basis = k["basis"].ctypes.data
+        for i in range(4):
+            w.conv_w[i] = k["cw"][i].ctypes.data
+            w.conv_b[i] = k["cb"][i].ctypes.data
+        w.lstm_w, w.lstm_r, w.lstm_b = k["lw"].ctypes.data, k["lr"].ctypes.data, k["lb"].ctypes.data
+        w.dec_w = k["dw"].ctypes.data
+        w.dec_b = float(np.asarray(weights["decoder.conv1d.bias"]).reshape(-1)[0])
+        self._lib = _lib.load()
+        self._handle = C.c_void_p()
+        _lib.check(self._lib.fw_vad_create(C.byref(w), C.byref(self._handle)))
+        self.n_threads = n_threads
+
+    def __call__(self, audio: np.ndarray, num_samples: int = 512, context_size_samples: int = 64) -> np.ndarray:
+        from . import _lib
+        assert audio.ndim == 1, "Input should be a 1D array"
+        assert audio.shape[0] % num_samples == 0, "Input size should be a multiple of num_samples"
+        if (num_samples, context_size_samples) != (512, 64):
+            raise ValueError("the Silero v6 network takes 512-sample windows with 64 samples of context")
+        # framing of the reference (vad.py:318-336): the context of a window is the tail of the previous one,
+        # zeros for the first; its in-place `context[-1] = 0` also clears the tail of the last (padding) window
+        win = np.array(audio, dtype=np.float32).reshape(-1, num_samples)
+        win[-1, -context_size_samples:] = 0
+        ctx = np.roll(win[:, -context_size_samples:], 1, axis=0)
+        windows = np.ascontiguousarray(np.concatenate([ctx, win], axis=1))
+        n = windows.shape[0]
+        h = np.zeros(128, dtype=np.float32)
+        c = np.zeros(128, dtype=np.float32)
+        probs = np.empty(n, dtype=np.float32)
+        _lib.check(self._lib.fw_vad_forward(self._handle, _lib.ptr(windows), n, self.n_threads, _lib.ptr(h),
+                                            _lib.ptr(c), _lib.ptr(probs)))
+        return probs
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                self._lib.fw_vad_free(h)
+            except Exception:
+                pass

@@ -251,6 +251,32 @@ int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const flo
 int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,
                           int32_t B, int32_t H, int32_t T, float* out);
 
+/* ---- Silero VAD network (host) ----------------------------------------------
+ * Replaces the reference's SileroVADModel (faster_whisper/vad.py:295-351: onnxruntime on the CPU, one thread,
+ * asset silero_vad_v6.onnx).  Host C++: needs no GPU.  The weights are the initializers of that ONNX file, passed
+ * as plain float32 arrays (faster_whisper_amd/onnx_lite.py reads them); the architecture is fixed to Silero v6:
+ *   stft_basis [258][256]; conv_w {[128][129][3], [64][128][3], [64][64][3], [128][64][3]} + conv_b;
+ *   lstm_w / lstm_r [512][128] in ONNX gate order i,o,f,c; lstm_b [1024] = Wb | Rb; dec_w [128], dec_b.
+ * fw_vad_forward: windows [n][576] float32 (64 samples of context + 512 new samples each, exactly what
+ * SileroVADModel.__call__ feeds the session, vad.py:318-336); h, c [128] LSTM state, updated in place (the
+ * windows are the LSTM's sequence; the reference carries h / c across its batches of 10 000 windows);
+ * probs [n] speech probability per window.  n_threads <= 0: all host cores. */
+typedef struct fw_vad fw_vad;
+typedef struct fw_vad_weights {
+  const float* stft_basis;
+  const float* conv_w[4];
+  const float* conv_b[4];
+  const float* lstm_w;
+  const float* lstm_r;
+  const float* lstm_b;
+  const float* dec_w;
+  float dec_b;
+} fw_vad_weights;
+int32_t fw_vad_create(const fw_vad_weights* w, fw_vad** out);
+int32_t fw_vad_forward(fw_vad* v, const float* windows, int64_t n, int32_t n_threads, float* h, float* c,
+                       float* probs);
+void fw_vad_free(fw_vad* v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,8 +84,11 @@ def test_fused_and_host_feature_paths_agree(wm):
     assert [s.avg_logprob for s in a] == pytest.approx([s.avg_logprob for s in b], abs=1e-5)
 
 
-def test_language_detection_and_errors(wm):
+def test_language_detection_and_errors(wm, monkeypatch):
+    from faster_whisper_amd import vad as fvad
     from faster_whisper_amd.transcribe import BatchedInferencePipeline
+    monkeypatch.setenv(fvad.ONNX_ENV, "/nonexistent/silero_vad_v6.onnx")   # the Silero weights are not on this box
+    monkeypatch.setattr(fvad, "_VAD_MODEL", None)
     cfg, w, model = wm
     audio, clips = _audio(2)
     pipe = BatchedInferencePipeline(model)
@@ -100,7 +103,7 @@ def test_language_detection_and_errors(wm):
     short = audio[:160000]
     segs, _ = pipe.transcribe(short, language="en", beam_size=1, max_new_tokens=4, vad_filter=False)  # < 30 s: one clip
     assert len(list(segs)) >= 1
-    with pytest.raises(RuntimeError, match="Silero"):   # default vad_filter=True needs speech probabilities (row f-3)
+    with pytest.raises(RuntimeError, match="Silero"):   # default vad_filter=True needs the VAD weights (or probabilities)
         pipe.transcribe(short, language="en", beam_size=1, max_new_tokens=4)
     # ... which can be supplied: all-speech probabilities keep the whole clip
     probs = np.full(len(short) // 512 + 1, 0.9, dtype=np.float32)

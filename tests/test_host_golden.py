@@ -135,7 +135,9 @@ def test_vad_state_machine_chunks_and_time_map(gold):
     assert any(len(v) > 2 for v in units["vad"].values())      # the fixtures are not trivially empty
 
 
-def test_vad_needs_probabilities():
+def test_vad_needs_probabilities(monkeypatch):
+    monkeypatch.setenv(fvad.ONNX_ENV, "/nonexistent/silero_vad_v6.onnx")   # no weights on this box
+    monkeypatch.setattr(fvad, "_VAD_MODEL", None)
     with pytest.raises(RuntimeError, match="Silero"):
         fvad.get_speech_timestamps(np.zeros(16000, np.float32))
     # a callable model is accepted and sees the padded audio
