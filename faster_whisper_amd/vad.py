@@ -6,11 +6,16 @@ Mirrors the reference's `faster_whisper/vad.py` interface (same names, argument 
     collect_chunks                  vad.py:186-243  merge speech spans into <= max_duration chunks
     SpeechTimestampsMap             vad.py:246-285  map times on the silence-free axis back to the recording
 
-The Silero VAD v6 network that produces the window probabilities (vad.py:295-351, an ONNX asset run by
-onnxruntime on one CPU thread in the reference) is row f-3 and not built: `get_speech_timestamps` takes the
-probabilities from `speech_probs=` or from a callable `vad_model=` (same contract as the reference's
-SileroVADModel.__call__: padded audio -> one probability per 512-sample window) and fails loudly otherwise.
-Everything downstream of the probabilities is integer/host logic and is complete.
+    SileroVADModel, get_vad_model   vad.py:288-351  the Silero VAD v6 network (row f-3)
+
+The network that produces the window probabilities is an ONNX asset the reference runs with onnxruntime on one
+CPU thread.  Here it is native host C++ behind the C ABI (`fw_vad_*`, csrc/vad_host.cpp: window-parallel front
+end on a thread pool, sequential LSTM recurrence); the ONNX file is only read for its weights (onnx_lite.py) and
+is NOT redistributed: `get_vad_model()` looks at $FWAMD_SILERO_VAD_ONNX, then at an installed `faster_whisper`
+package, and fails loudly otherwise.  `get_speech_timestamps` also accepts the probabilities directly
+(`speech_probs=`) or any callable with SileroVADModel's contract (`vad_model=`).  Parity of the network with the
+reference's onnxruntime run is unpinned (onnxruntime absent); the state machine downstream is pinned
+(tests/golden/host_units.json).
 """
 import bisect
 from dataclasses import dataclass
