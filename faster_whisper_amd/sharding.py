@@ -50,15 +50,19 @@ def broadcast_blob(blob: Optional[np.ndarray], rank: int, local_rank: int):
     return t
 
 
+RECORD_EXTRA = 5   # int32 words besides the ids: length + two float64
+
+
 def encode_records(results, max_len: int) -> np.ndarray:
-    """fixed-size int32 record per chunk: [len, ids[max_len], score_bits, no_speech_bits]"""
-    rec = np.zeros((len(results), max_len + 3), dtype=np.int32)
+    """fixed-size int32 record per chunk: [len, ids[max_len], score (float64, 2 words), no_speech_prob (float64,
+    2 words)] — float64 so that rank 0 sees bit-for-bit what a serial run computes (avg_logprob is a Python float)"""
+    rec = np.zeros((len(results), max_len + RECORD_EXTRA), dtype=np.int32)
     for i, r in enumerate(results):
         ids = r.sequences_ids[0][:max_len]
         rec[i, 0] = len(ids)
         rec[i, 1:1 + len(ids)] = ids
-        rec[i, max_len + 1] = np.float32(r.scores[0] if r.scores else 0.0).view(np.int32)
-        rec[i, max_len + 2] = np.float32(r.no_speech_prob).view(np.int32)
+        rec[i, max_len + 1:max_len + 3] = np.array([r.scores[0] if r.scores else 0.0], dtype=np.float64).view(np.int32)
+        rec[i, max_len + 3:max_len + 5] = np.array([r.no_speech_prob], dtype=np.float64).view(np.int32)
     return rec
 
 
@@ -66,8 +70,9 @@ def decode_records(rec: np.ndarray, max_len: int):
     out = []
     for row in rec:
         n = int(row[0])
-        out.append((row[1:1 + n].tolist(), float(row[max_len + 1:max_len + 2].view(np.float32)[0]),
-                    float(row[max_len + 2:max_len + 3].view(np.float32)[0])))
+        row = np.ascontiguousarray(row)
+        out.append((row[1:1 + n].tolist(), float(row[max_len + 1:max_len + 3].view(np.float64)[0]),
+                    float(row[max_len + 3:max_len + 5].view(np.float64)[0])))
     return out
 
 
@@ -79,7 +84,7 @@ def gather_results(results, max_len: int, rank: int, world: int, local_rank: int
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     n_max = max(counts) if counts is not None else len(results)
-    rec = np.zeros((n_max, max_len + 3), dtype=np.int32)
+    rec = np.zeros((n_max, max_len + RECORD_EXTRA), dtype=np.int32)
     if len(results):
         rec[:len(results)] = encode_records(results, max_len)
     t = torch.from_numpy(rec).to(dev)

@@ -691,19 +691,37 @@ class WhisperModel:
         chunk's text tokens in ONE backend call, merges punctuation into neighbouring words, clamps
         over-long words at sentence / pause / segment boundaries and stores `words` in every sub-segment
         (transcribe.py:1567-1696).  -> end time of the last word (carried into the next call)."""
-        from .words import assign_words, clamp_sentence_boundaries, merge_punctuations
         if len(segments) == 0:
             return None
+        aligned = self.align_words(segments, tokenizer, encoder_output, num_frames, prepend_punctuations,
+                                   append_punctuations)
+        return self.apply_word_alignments(segments, aligned, last_speech_timestamp)
+
+    def align_words(self, segments: List[List[dict]], tokenizer: Tokenizer, encoder_output: StorageView, num_frames,
+                    prepend_punctuations: str, append_punctuations: str) -> List[dict]:
+        """Chunk-local half of add_word_timestamps: one backend `align` call for all chunks, then per chunk the
+        word list with sentence-boundary clamping and punctuation merged.  Needs the encoder output, i.e. runs
+        on the rank that decoded the chunks; the result is plain data (picklable) for `apply_word_alignments`."""
+        from .words import clamp_sentence_boundaries, merge_punctuations
         per_sub = [[[t for t in sub["tokens"] if t < tokenizer.eot] for sub in chunk] for chunk in segments]
         text_tokens = [[t for sub in subs for t in sub] for subs in per_sub]
         alignments = self.find_alignment(tokenizer, text_tokens, encoder_output, num_frames)
-        limits = []
-        for alignment in alignments:
-            limits.append(clamp_sentence_boundaries(alignment))
+        out = []
+        for alignment, subs in zip(alignments, per_sub):
+            median, longest = clamp_sentence_boundaries(alignment)
             merge_punctuations(alignment, prepend_punctuations, append_punctuations)
-        for chunk, subs, alignment, (median, longest) in zip(segments, per_sub, alignments, limits):
-            last_speech_timestamp = assign_words(chunk, alignment, subs, chunk[0]["seek"] / self.frames_per_second,
-                                                 median, longest, last_speech_timestamp)
+            out.append(dict(words=alignment, median=median, longest=longest, tokens_per_subsegment=subs))
+        return out
+
+    def apply_word_alignments(self, segments: List[List[dict]], aligned: List[dict],
+                              last_speech_timestamp: float) -> float:
+        """Sequential half: distributes every chunk's words over its sub-segments; the pause heuristics chain
+        through `last_speech_timestamp` from chunk to chunk, so this runs in chunk order on one process."""
+        from .words import assign_words
+        for chunk, a in zip(segments, aligned):
+            last_speech_timestamp = assign_words(chunk, a["words"], a["tokens_per_subsegment"],
+                                                 chunk[0]["seek"] / self.frames_per_second, a["median"], a["longest"],
+                                                 last_speech_timestamp)
         return last_speech_timestamp
 
     def detect_language(self, audio: Optional[np.ndarray] = None, features: Optional[np.ndarray] = None,
@@ -784,6 +802,16 @@ class BatchedInferencePipeline:
 
     def _segment_outputs(self, outputs, tokenizer, chunks_metadata, options, encoder_output=None):
         m = self.model
+        segmented, sizes = self._split_outputs(outputs, tokenizer, chunks_metadata)
+        if options.word_timestamps:
+            self.last_speech_timestamp = m.add_word_timestamps(
+                segmented, tokenizer, encoder_output, sizes, options.prepend_punctuations,
+                options.append_punctuations, self.last_speech_timestamp)
+        return segmented
+
+    def _split_outputs(self, outputs, tokenizer, chunks_metadata):
+        """per chunk: its sub-segment dicts (timestamp splitting) and its size in frames"""
+        m = self.model
         segmented, sizes = [], []
         for meta, out in zip(chunks_metadata, outputs):
             duration = meta["duration"]
@@ -798,14 +826,7 @@ class BatchedInferencePipeline:
                      compression_ratio=get_compression_ratio(tokenizer.decode(s["tokens"]) or " "),
                      seek=int(meta["offset"] * m.frames_per_second))
                 for s in subs])
-        if options.word_timestamps:
-            if encoder_output is None:
-                raise NotImplementedError("word_timestamps with shard=True: the alignment needs the encoder output "
-                                          "of the rank that decoded the chunk (not gathered yet)")
-            self.last_speech_timestamp = m.add_word_timestamps(
-                segmented, tokenizer, encoder_output, sizes, options.prepend_punctuations,
-                options.append_punctuations, self.last_speech_timestamp)
-        return segmented
+        return segmented, sizes
 
     # ---- the public entry point ---------------------------------------------------------
     def transcribe(self, audio: Union[str, np.ndarray], language: Optional[str] = None, task: str = "transcribe",
@@ -959,17 +980,31 @@ class BatchedInferencePipeline:
         # every rank walks the same number of batch rounds so the per-round gather lines up
         rounds = max((b[1] - b[0] + batch_size - 1) // batch_size for b in bounds) if n else 0
         per_rank_outputs = [[] for _ in range(world)]
+        per_rank_aligned = [[] for _ in range(world)]
         for rnd in range(rounds):
             i0 = lo + rnd * batch_size
             i1 = min(hi, i0 + batch_size)
-            outs = []
+            outs, aligned = [], []
             if i0 < i1:
                 chunks = audio_chunks[i0:i1]
                 if fused_features:
-                    _, outs = self.generate_segment_batched(None, tokenizer, options, audio_chunks=chunks)
+                    enc, outs = self.generate_segment_batched(None, tokenizer, options, audio_chunks=chunks)
                 else:
                     feats = m.model.log_mel(chunks)
-                    _, outs = self.generate_segment_batched(feats, tokenizer, options)
+                    enc, outs = self.generate_segment_batched(feats, tokenizer, options)
+                if options.word_timestamps:
+                    # the chunk-local half of the word timing runs where the encoder output lives; the
+                    # sequential half (pause heuristics chained through last_speech_timestamp) on rank 0 below
+                    local, sizes = self._split_outputs(outs, tokenizer, chunks_metadata[i0:i1])
+                    aligned = m.align_words(local, tokenizer, enc, sizes, options.prepend_punctuations,
+                                            options.append_punctuations)
+            if options.word_timestamps and world > 1:
+                import torch.distributed as dist
+                bucket = [None] * world if rank == 0 else None
+                dist.gather_object(aligned, bucket, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        per_rank_aligned[r].extend(bucket[r])
             if world == 1:
                 per_rank_outputs[0].extend(outs)
             else:
@@ -985,12 +1020,16 @@ class BatchedInferencePipeline:
         if rank != 0:
             return
         ordered = [o for r in range(world) for o in per_rank_outputs[r]]
-        results = self._segment_outputs(ordered, tokenizer, chunks_metadata, options)
+        results, _ = self._split_outputs(ordered, tokenizer, chunks_metadata)
+        if options.word_timestamps:
+            ordered_aligned = [a for r in range(world) for a in per_rank_aligned[r]]
+            self.last_speech_timestamp = m.apply_word_alignments(results, ordered_aligned, self.last_speech_timestamp)
         for result in results:
             for seg in result:
                 seg_idx += 1
                 yield Segment(seek=seg["seek"], id=seg_idx, text=seg["text"], start=round(seg["start"], 3),
-                              end=round(seg["end"], 3), words=None, tokens=seg["tokens"],
+                              end=round(seg["end"], 3), tokens=seg["tokens"],
+                              words=(None if not options.word_timestamps else [Word(**w) for w in seg["words"]]),
                               avg_logprob=seg["avg_logprob"], no_speech_prob=seg["no_speech_prob"],
                               compression_ratio=seg["compression_ratio"], temperature=options.temperatures[0])
         self.last_speech_timestamp = 0.0

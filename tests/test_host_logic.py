@@ -105,7 +105,7 @@ def test_result_records_roundtrip():
             self.sequences_ids, self.scores, self.no_speech_prob = [ids], [s], n
     rs = [R([1, 2, 3], -0.25, 0.5), R([], -1.5, 0.0), R(list(range(40)), 0.0, 1.0)]
     rec = encode_records(rs, 32)
-    assert rec.shape == (3, 35) and rec.dtype == np.int32
+    assert rec.shape == (3, 37) and rec.dtype == np.int32   # 1 + 32 ids + 2 float64
     back = decode_records(rec, 32)
     assert back[0] == ([1, 2, 3], -0.25, 0.5) and back[1] == ([], -1.5, 0.0)
     assert back[2][0] == list(range(32))   # truncated to max_len

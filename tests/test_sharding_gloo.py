@@ -91,6 +91,27 @@ def _worker(rank, world, port, tmpdir):
                 np.array([[s.id, s.seek, len(s.tokens), s.tokens[0], round(s.avg_logprob * 1e6)] for s in segs]))
     else:
         assert segs == []
+    # 4) the whole batched pipeline with WORD TIMESTAMPS, sharded: chunk-local alignment on the rank that holds
+    #    the encoder output, gather_object of the word lists, sequential pause heuristics on rank 0
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_golden import _plain, make_model
+    from faster_whisper_amd import get_config
+    from faster_whisper_amd.transcribe import BatchedInferencePipeline
+    from oracle import host_scenarios as hs
+    from oracle import micro_tokenizer
+    sc = hs.SCENARIOS["bat_clips_words"]
+    model = make_model(get_config("micro"), micro_tokenizer.build())
+    segments, info = BatchedInferencePipeline(model).transcribe(hs.synth_audio(*sc["audio"]), shard=True,
+                                                                **json.loads(json.dumps(sc["kwargs"])))
+    segments = [_plain(x) for x in segments]
+    if rank == 0:
+        with open(os.path.join(tmpdir, "sharded_words.json"), "w") as f:
+            json.dump(segments, f)
+    else:
+        assert segments == []
+        # this rank decoded and aligned only its half of the chunks
+        assert [c[0] for c in model.model.calls].count("align") >= 1
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,3 +126,14 @@ def test_two_rank_gloo(tmp_path):
     ref = np.array([[s.id, s.seek, len(s.tokens), s.tokens[0], round(s.avg_logprob * 1e6)] for s in serial])
     assert sharded.shape == ref.shape == (11, 5)
     assert np.array_equal(sharded, ref)
+    # the sharded word-timestamp run reproduces the REFERENCE's serial result (tests/golden/host_scenarios.json)
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_golden import _close
+    with open(os.path.join(ROOT, "tests", "golden", "host_scenarios.json")) as f:
+        want = json.load(f)["bat_clips_words"]["segments"]
+    with open(tmp_path / "sharded_words.json") as f:
+        got = json.load(f)
+    assert len(got) == len(want) and sum(len(s["words"]) for s in got) > 50
+    for i, (g, w) in enumerate(zip(got, want)):
+        _close(g, w, f"segments[{i}]")
