@@ -13,7 +13,14 @@ Pinning status
     that is neither in /root/reference nor installed, and no Whisper checkpoint is on
     disk.  The restatement follows openai-whisper / CTranslate2 4.x published behaviour
      and is anchored on the reference's call sites
-    (transcribe.py:222-236, :1433-1459, :1709-1715, :1823) and on an architecture
-    cross-check against the installed `transformers` Whisper implementation
-    (tests/test_oracle_arch.py).
+    (transcribe.py:222-236, :1433-1459, :1709-1715, :1823) and on cross-checks against the
+    installed `transformers` Whisper implementation: architecture (tests/test_oracle_arch.py),
+    timestamp / suppress logits rules, median filter and DTW (tests/test_oracle_vs_hf_rules.py:
+    identical on random inputs).  Beam-search bookkeeping and int8 conventions stay [CT2-ext].
+  * host logic of the callers (prompts, seek loop, temperature fallback, word timestamps, VAD
+    state machine, chunk merging; `oracle.scripted_backend`, `oracle.micro_tokenizer`,
+    `oracle.host_scenarios`): PINNED — `oracle/gen_golden_host.py` runs the reference's own
+    transcribe.py / tokenizer.py / vad.py in the build container; fixtures under `tests/golden/`.
+  * Silero VAD network (`oracle.silero`): PARITY UNPINNED (onnxruntime absent); restates the ONNX
+    graph of the reference's asset, plausibility-checked on the reference's speech fixture.
 """
