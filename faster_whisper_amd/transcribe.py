@@ -366,7 +366,8 @@ class WhisperModel:
                                 "True; setting to False instead.")
             multilingual = False
         if not isinstance(audio, np.ndarray):
-            raise NotImplementedError("audio decoding (PyAV) is outside this tier: pass a 16 kHz float32 ndarray")
+            from .audio import decode_audio   # path / file object: WAVE natively, other containers through PyAV
+            audio = decode_audio(audio, sampling_rate=sr)
         duration = audio.shape[0] / sr
         duration_after_vad = duration
         speech_chunks = None
@@ -857,7 +858,8 @@ class BatchedInferencePipeline:
                              "True; setting to False instead.")
             multilingual = False
         if not isinstance(audio, np.ndarray):
-            raise NotImplementedError("audio decoding (PyAV) is outside this tier: pass a 16 kHz float32 ndarray")
+            from .audio import decode_audio   # path / file object: WAVE natively, other containers through PyAV
+            audio = decode_audio(audio, sampling_rate=sr)
         audio = np.asarray(audio, dtype=np.float32)
         duration = audio.shape[0] / sr
         chunk_length = chunk_length or m.feature_extractor.chunk_length
