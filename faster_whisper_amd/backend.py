@@ -244,6 +244,7 @@ class Whisper:
                                                    (p.value, n.value)))
         self._rr = itertools.count()
         self._tls = threading.local()
+        self.inter_threads = len(self._replicas)   # batches the host drivers may keep in flight
 
     # ---- properties read by the reference host code -------------------------------------
     @property

@@ -958,12 +958,42 @@ class BatchedInferencePipeline:
         n = len(audio_chunks)
         seg_idx = 0
         if world == 1:
-            # single process: batch by batch, segments are yielded as soon as their batch is decoded
-            for i in range(0, n, batch_size):
+            # single process: segments are yielded as soon as their batch is decoded.  With worker replicas
+            # (WhisperModel(num_workers=W) -> backend inter_threads) W batches are kept in flight on the GPU:
+            # the batches of a recording are independent (`condition_on_previous_text=False`), only the
+            # word-timestamp pause heuristics chain through last_speech_timestamp, and those run here, in order.
+            workers = int(getattr(m.model, "inter_threads", 1) or 1)
+
+            def decode_batch(i):
                 chunks = audio_chunks[i:i + batch_size]
                 feats = None if fused_features else m.model.log_mel(chunks)
-                results = self.forward(feats, tokenizer, chunks_metadata[i:i + batch_size], options,
-                                       audio_chunks=chunks if fused_features else None)
+                enc, outs = self.generate_segment_batched(feats, tokenizer, options,
+                                                          audio_chunks=chunks if fused_features else None)
+                local, sizes = self._split_outputs(outs, tokenizer, chunks_metadata[i:i + batch_size])
+                aligned = (m.align_words(local, tokenizer, enc, sizes, options.prepend_punctuations,
+                                         options.append_punctuations) if options.word_timestamps else None)
+                return local, aligned
+
+            def batches():
+                starts = list(range(0, n, batch_size))
+                if workers <= 1 or len(starts) <= 1:
+                    for i in starts:
+                        yield decode_batch(i)
+                    return
+                from collections import deque
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    pending = deque()
+                    for i in starts:
+                        pending.append(pool.submit(decode_batch, i))
+                        if len(pending) >= workers:
+                            yield pending.popleft().result()
+                    while pending:
+                        yield pending.popleft().result()
+
+            for results, aligned in batches():
+                if options.word_timestamps:
+                    self.last_speech_timestamp = m.apply_word_alignments(results, aligned, self.last_speech_timestamp)
                 for result in results:
                     for seg in result:
                         seg_idx += 1

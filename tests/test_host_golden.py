@@ -168,3 +168,25 @@ def test_word_splitting_and_punctuation_merge(gold, hf_tok):
             assert alignment == units["merge"][f"{lang}|{text}"]
             n += 1
     assert n == sum(len(t) for t in hs.SPLIT_TEXTS.values())
+
+
+@pytest.mark.parametrize("name", ["bat_clips_words", "bat_vad"])
+def test_batches_in_flight_keep_the_serial_result(gold, hf_tok, name):
+    """worker replicas (backend.inter_threads > 1): several batches are decoded concurrently, the segments —
+    including the word-timestamp heuristics that chain from batch to batch — stay those of the serial run"""
+    scen, _ = gold
+    sc = hs.SCENARIOS[name]
+    model = make_model(get_config("micro"), hf_tok)
+    model.model.inter_threads = 3
+    audio = hs.synth_audio(*sc["audio"])
+    kwargs = json.loads(json.dumps(sc["kwargs"]))
+    kwargs["batch_size"] = 1                                    # many batches -> real overlap
+    if kwargs.get("vad_filter"):
+        kwargs["vad_speech_probs"] = hs.speech_probs(np.pad(audio, (0, 512 - audio.shape[0] % 512)))
+    segments, _ = BatchedInferencePipeline(model).transcribe(audio, **kwargs)
+    segments = [_plain(s) for s in segments]
+    want = scen[name]["segments"]
+    assert len(segments) == len(want)
+    for i, (g, w) in enumerate(zip(segments, want)):
+        _close(g, w, f"{name}.segments[{i}]")
+    assert [c[0] for c in model.model.calls].count("generate") >= 4
