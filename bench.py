@@ -215,7 +215,8 @@ def main():
                     fam[k] = {"GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
             out["families_rate"] = fam
         # ---- CPU baseline: the oracle (torch fp32 port) on a bounded sample of the same workload ----
-        if not args.no_cpu_baseline:
+        # (reported at N = 1 only: at N > 1 the other ranks would idle at the final barrier while it runs)
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks[0], prompt, args.beam, L, gen_kw)
         print(json.dumps(out), flush=True)
     model.free_staged(staged)
