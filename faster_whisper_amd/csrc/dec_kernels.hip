@@ -539,6 +539,135 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 }
 
 // ------------------------------------------------------------------------------------
+// Row-loop form of the fragment-major skinny GEMM (experiment, FWAMD_FRAG_ROWLOOP=1; K <= 1280):
+// one workgroup = NT column tiles x ALL row tiles.  Its weight fragments (NT x 10 k-steps per wave) are loaded
+// ONCE and stay in registers while the row tiles are walked two at a time, so a weight byte crosses the fabric
+// exactly once (the tiled form re-fetches it per row group: FETCH_SIZE 10.4 MB vs 6.55 MB algorithmic) at the
+// price of 2.5x fewer, longer workgroups.
+// ------------------------------------------------------------------------------------
+template <int WAVES, bool LNF, int NT>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_rowloop_kernel(
+    const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
+    const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
+    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
+  constexpr int RT = 2, PER = 10;
+  __shared__ float red[WAVES][RT * NT][64][4];
+  __shared__ float red_s[WAVES][RT][16][2];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int ct0 = blockIdx.x * NT;
+  const int n_rt = (R + 15) >> 4;
+  const int KS = K >> 5;
+  const int per = (KS + WAVES - 1) / WAVES;          // <= PER (checked by the launcher)
+  const int ks0 = wave * per;
+  int nks = KS - ks0;
+  if (nks > per) nks = per;
+  if (nks < 0) nks = 0;
+  half8_t wv[NT][PER];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const half8_t* wp = reinterpret_cast<const half8_t*>(Wf) + ((size_t)(ct0 + b) * KS + ks0) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int jj = j < nks ? j : (nks > 0 ? nks - 1 : 0);
+      wv[b][j] = nks > 0 ? wp[(size_t)jj * 64] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  for (int rt0 = 0; rt0 < n_rt; rt0 += RT) {
+    floatx4 acc[RT][NT];
+    float rs[RT], rq[RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      rs[a] = 0.f; rq[a] = 0.f;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = floatx4{0, 0, 0, 0};
+    }
+    if (nks > 0) {
+      half8_t xv[RT][PER];
+#pragma unroll
+      for (int a = 0; a < RT; ++a) {
+        int rt = rt0 + a;
+        if (rt > n_rt - 1) rt = n_rt - 1;
+        const half8_t* xp = reinterpret_cast<const half8_t*>(xf) + ((size_t)rt * KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) xv[a][j] = xp[(size_t)(j < nks ? j : nks - 1) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (j < nks) {
+#pragma unroll
+          for (int a = 0; a < RT; ++a) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[b][j], xv[a][j], acc[a][b], 0, 0, 0);
+            if (LNF) {
+              const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const half2_t h2 = {xv[a][j][2 * e], xv[a][j][2 * e + 1]};
+                rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
+                rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      if (LNF) {
+        float sa = rs[a], sb = rq[a];
+        sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+        if (g == 0) { red_s[wave][a][i][0] = sa; red_s[wave][a][i][1] = sb; }
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][a * NT + b][lane][e] = acc[a][b][e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        if ((a * NT + b) % WAVES != wave) continue;
+        const int row = (rt0 + a) * 16 + i;
+        if (rt0 + a >= n_rt || row >= R) continue;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += red[w][a * NT + b][lane][e];
+        float mu = 0.f, rstd = 1.f;
+        if (LNF) {
+          float sa = 0.f, sb = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) { sa += red_s[w][a][i][0]; sb += red_s[w][a][i][1]; }
+          mu = sa / (float)K;
+          rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
+        }
+        const int n = (ct0 + b) * 16 + 4 * g;
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float tv = v[e];
+          if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
+          else if (bias) tv += (float)bias[n + e];
+          if (act == 1) tv = gelu_erf(tv);
+          if (res) tv += (float)res[(size_t)row * ldr + n + e];
+          o[e] = (half_t)tv;
+        }
+        if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
+        if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
+      }
+    }
+    __syncthreads();   // the reduction buffers are rewritten by the next pair of row tiles
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // K13: decoder self-attention for one (row, head), KV cache with slot indirection.
 // cache layout [slot][H][n_ctx][64].  The new K/V (position pos) are written to the row's
 // own slot; older positions are read from kvidx[row][p] (slot inside the chunk).
@@ -1390,6 +1519,19 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
   static const int env_w = [] { const char* e = getenv("FWAMD_FRAG_WAVES"); return e ? atoi(e) : 0; }();
   const int waves = (env_w == 4 || env_w == 8) ? env_w : (K >= 2560 ? 8 : 4);
   const bool lnf = s1 != nullptr;
+  // experiment (profiles/README.md): row-loop form, weights cross the fabric once; needs K/32/waves <= 10
+  static const bool rowloop = [] { const char* e = getenv("FWAMD_FRAG_ROWLOOP"); return e && e[0] == '1'; }();
+  if (rowloop && ((K >> 5) + waves - 1) / waves <= 10 && N % 32 == 0) {
+    const dim3 grid(N / 32, 1);
+    if (waves == 8) {
+      if (lnf) dec_gemm_frag_rowloop_kernel<8, true, 2><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+      else dec_gemm_frag_rowloop_kernel<8, false, 2><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    } else {
+      if (lnf) dec_gemm_frag_rowloop_kernel<4, true, 2><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+      else dec_gemm_frag_rowloop_kernel<4, false, 2><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    }
+    return 0;
+  }
 #define FG(L, A, B) frag_go<L, A, B>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
   if (env_rt == 2 && env_nt == 2) { if (lnf) FG(true, 2, 2); else FG(false, 2, 2); }
   else if (env_rt == 2) { if (lnf) FG(true, 2, 1); else FG(false, 2, 1); }
