@@ -109,3 +109,17 @@ def test_result_records_roundtrip():
     back = decode_records(rec, 32)
     assert back[0] == ([1, 2, 3], -0.25, 0.5) and back[1] == ([], -1.5, 0.0)
     assert back[2][0] == list(range(32))   # truncated to max_len
+
+
+def test_bench_pipeline_measure_runs_on_a_scripted_backend():
+    """bench.py's secondary end-to-end number: exercised here without a GPU (scripted backend), and a broken
+    backend must be reported, never raised"""
+    import bench
+    from oracle import micro_tokenizer
+    from oracle.scripted_backend import ScriptedBackend
+    cfg = get_config("micro")
+    backend = ScriptedBackend(cfg, micro_tokenizer.build())
+    backend.inter_threads = 3
+    r = bench.pipeline_rtf(backend, cfg, 7, 2, 5, 20)
+    assert r["segments"] == 7 and r["tokens"] == 7 * 20 and r["audio_s"] == 210.0 and r["value"] > 0
+    assert "error" in bench.pipeline_rtf(object(), cfg, 2, 2, 5, 20)
