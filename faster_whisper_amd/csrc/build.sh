@@ -6,14 +6,14 @@ OUT=../libfwamd.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 mkdir -p build
 pids=()
-for f in logmel gemm rowops attn_enc engine decoder dec_kernels; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ dec_kernels.h -nt build/$f.o ] || [ ../../include/fwamd.h -nt build/$f.o ]; then
+for f in logmel gemm rowops attn_enc engine decoder dec_kernels vad; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ dec_kernels.h -nt build/$f.o ] || [ ../../include/fwamd.h -nt build/$f.o ] || [ vad_model.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 # host-only C++ (Silero VAD network): g++, with AVX2 / AVX-512 clones selected at run time (target_clones)
-if [ ! -f build/vad_host.o ] || [ vad_host.cpp -nt build/vad_host.o ] || [ ../../include/fwamd.h -nt build/vad_host.o ]; then
+if [ ! -f build/vad_host.o ] || [ vad_host.cpp -nt build/vad_host.o ] || [ ../../include/fwamd.h -nt build/vad_host.o ] || [ vad_model.h -nt build/vad_host.o ]; then
   g++ -O3 -std=c++17 -fPIC -Wall -c vad_host.cpp -o build/vad_host.o &
   pids+=($!)
 fi

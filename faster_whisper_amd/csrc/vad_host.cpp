@@ -34,24 +34,9 @@ void set_error(const char* fmt, ...);
     }                              \
   } while (0)
 
+#include "vad_model.h"
+
 namespace {
-
-constexpr int kWin = 576, kPad = 128, kPadded = kWin + 2 * kPad, kTaps = 256, kHop = 128;
-constexpr int kBins = 129, kFrames = 4, kHidden = 128, kGates = 4 * kHidden;
-constexpr int kC[5] = {kBins, 128, 64, 64, 128};      // channels through the four convolutions
-constexpr int kT[5] = {kFrames, 4, 2, 1, 1};          // frames after each convolution
-constexpr int kStride[4] = {1, 2, 2, 1};
-
-// All matrices are stored TRANSPOSED (reduction index outermost, output index contiguous): every inner loop then
-// runs over independent outputs, which the compiler vectorises without re-associating the sums (the per-output
-// summation order stays the sequential one of the definition).
-struct Vad {
-  std::vector<float> basis_t;               // [256 taps][258]
-  std::vector<float> cw_t[4], cb[4];        // [Cin][3][Cout], [Cout]
-  std::vector<float> lw_t, lr_t, lb;        // [128][512], [128][512], [512] (Wb + Rb)
-  std::vector<float> dw;                    // [128]
-  float db = 0.f;
-};
 
 #define VAD_SIMD __attribute__((target_clones("avx512f", "avx2", "default")))
 
@@ -167,10 +152,6 @@ VAD_SIMD float lstm_step(const Vad& v, const float* gx, float* h, float* c) {
 
 }  // namespace
 
-struct fw_vad {
-  Vad impl;
-};
-
 extern "C" {
 
 int32_t fw_vad_create(const fw_vad_weights* w, fw_vad** out) {
@@ -206,7 +187,10 @@ int32_t fw_vad_create(const fw_vad_weights* w, fw_vad** out) {
   return FW_OK;
 }
 
-void fw_vad_free(fw_vad* v) { delete v; }
+void fw_vad_free(fw_vad* v) {
+  if (v && v->dev) fw_vad_dev_release(v->dev);
+  delete v;
+}
 
 int32_t fw_vad_forward(fw_vad* fv, const float* windows, int64_t n, int32_t n_threads, float* h, float* c,
                        float* probs) {

@@ -232,7 +232,9 @@ class SileroVADModel:
               "decoder.conv1d.weight": (1, 128, 1)}
 
     def __init__(self, path: Optional[str] = None, weights: Optional[Dict[str, np.ndarray]] = None,
-                 n_threads: int = 0):
+                 n_threads: int = 0, device: str = "cpu", device_index: int = 0):
+        """device="cpu" (default): host C++ on `n_threads` threads (0 = all cores).  device="cuda": the HIP kernels
+        of csrc/vad.hip — opt-in until they have been validated on hardware."""
         import ctypes as C
         from . import _lib, onnx_lite
         if weights is None:
@@ -263,6 +265,9 @@ class SileroVADModel:
         self._handle = C.c_void_p()
         _lib.check(self._lib.fw_vad_create(C.byref(w), C.byref(self._handle)))
         self.n_threads = n_threads
+        if device not in ("cpu", "cuda"):
+            raise ValueError(f"unsupported device '{device}'")
+        self.device, self.device_index = device, device_index
 
     def __call__(self, audio: np.ndarray, num_samples: int = 512, context_size_samples: int = 64) -> np.ndarray:
         from . import _lib
@@ -280,8 +285,12 @@ class SileroVADModel:
         h = np.zeros(128, dtype=np.float32)
         c = np.zeros(128, dtype=np.float32)
         probs = np.empty(n, dtype=np.float32)
-        _lib.check(self._lib.fw_vad_forward(self._handle, _lib.ptr(windows), n, self.n_threads, _lib.ptr(h),
-                                            _lib.ptr(c), _lib.ptr(probs)))
+        if self.device == "cuda":
+            _lib.check(self._lib.fw_vad_forward_dev(self._handle, self.device_index, _lib.ptr(windows), n, _lib.ptr(h),
+                                                    _lib.ptr(c), _lib.ptr(probs)))
+        else:
+            _lib.check(self._lib.fw_vad_forward(self._handle, _lib.ptr(windows), n, self.n_threads, _lib.ptr(h),
+                                                _lib.ptr(c), _lib.ptr(probs)))
         return probs
 
     def __del__(self):

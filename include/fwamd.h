@@ -276,6 +276,12 @@ int32_t fw_vad_create(const fw_vad_weights* w, fw_vad** out);
 int32_t fw_vad_forward(fw_vad* v, const float* windows, int64_t n, int32_t n_threads, float* h, float* c,
                        float* probs);
 void fw_vad_free(fw_vad* v);
+/* Same computation on HIP device `device_index` (csrc/vad.hip: one workgroup per window for the front end, one
+ * persistent workgroup for the LSTM recurrence); host pointers in and out.  Written after round 1's GPU budget
+ * was spent: compiles, not yet validated on hardware — fw_vad_forward (host) is what the Python front uses by
+ * default. */
+int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows, int64_t n, float* h, float* c,
+                           float* probs);
 
 #ifdef __cplusplus
 }
