@@ -729,10 +729,14 @@ class WhisperModel:
                         vad_filter: bool = False, vad_parameters=None, language_detection_segments: int = 1,
                         language_detection_threshold: float = 0.5):
         assert audio is not None or features is not None, "Either `audio` or `features` must be provided."
-        if vad_filter:
-            raise NotImplementedError("Silero VAD is a 'next' row of this tier (SURVEY.md section 8f-3)")
         fe = self.feature_extractor
         if audio is not None:
+            if vad_filter:   # keep only the speech before looking at the first segments (transcribe.py:1802-1806)
+                from .vad import VadOptions, collect_chunks, get_speech_timestamps
+                if isinstance(vad_parameters, dict):
+                    vad_parameters = VadOptions(**vad_parameters)
+                speech_chunks = get_speech_timestamps(audio, vad_parameters)
+                audio = np.concatenate(collect_chunks(audio, speech_chunks)[0], axis=0)
             features = fe(audio[: language_detection_segments * fe.n_samples])
         features = features[..., : language_detection_segments * fe.nb_max_frames]
         seen = {}

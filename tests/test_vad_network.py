@@ -168,3 +168,24 @@ def test_real_weights_on_the_reference_speech_fixture():
     # end to end: the state machine finds one speech span inside the padded recording
     spans = vad.get_speech_timestamps(audio, vad.VadOptions(min_silence_duration_ms=300), vad_model=model)
     assert len(spans) >= 1 and spans[0]["start"] > 16000 and spans[-1]["end"] < len(audio) - 16000
+
+
+@pytest.mark.skipif(_real_onnx() is None, reason="silero_vad_v6.onnx not available on this box")
+def test_detect_language_with_vad_filter(monkeypatch):
+    """WhisperModel.detect_language(audio, vad_filter=True): the speech is cut out before the first segments are
+    looked at (transcribe.py:1802-1806) — here with the native VAD and a scripted backend"""
+    from faster_whisper_amd import get_config
+    from oracle import micro_tokenizer
+    from test_host_golden import make_model
+    monkeypatch.setenv(vad.ONNX_ENV, _real_onnx())
+    monkeypatch.setattr(vad, "_VAD_MODEL", None)
+    model = make_model(get_config("micro"), micro_tokenizer.build())
+    speech = np.load(os.path.join(GOLD, "speech_pcm.npz"))["pcm"].astype(np.float32)
+    audio = np.concatenate([np.zeros(48000, np.float32), speech, np.zeros(48000, np.float32)])
+    lang, prob, all_probs = model.detect_language(audio=audio, vad_filter=True,
+                                                  vad_parameters=dict(min_silence_duration_ms=300))
+    lang2, prob2, _ = model.detect_language(audio=audio)
+    assert lang in ("en", "zh", "de", "es") and 0 < prob <= 1 and len(all_probs) == 4
+    # the silence was removed: the encoder saw a different (shorter, louder) window than without the filter
+    enc_calls = [c[1] for c in model.model.calls if c[0] == "encode"]
+    assert len(enc_calls) == 2 and enc_calls[0] != enc_calls[1]
