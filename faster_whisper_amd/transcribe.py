@@ -828,7 +828,7 @@ class BatchedInferencePipeline:
             segmented.append([
                 dict(text=tokenizer.decode(s["tokens"]), avg_logprob=out["avg_logprob"],
                      no_speech_prob=out["no_speech_prob"], tokens=s["tokens"], start=s["start"], end=s["end"],
-                     compression_ratio=get_compression_ratio(tokenizer.decode(s["tokens"]) or " "),
+                     compression_ratio=get_compression_ratio(tokenizer.decode(s["tokens"])),
                      seek=int(meta["offset"] * m.frames_per_second))
                 for s in subs])
         return segmented, sizes
@@ -897,6 +897,9 @@ class BatchedInferencePipeline:
                                      "transcribed", i)
                 chunks_metadata.append({"offset": clip["start"] / sr, "duration": d, "segments": [clip]})
         duration_after_vad = sum(c["end"] - c["start"] for c in clips) / sr
+        # the reference formats the removed duration for its log line, which asserts it is not negative
+        # (transcribe.py:458-461, utils.py:124): clips that add up to more than the recording are rejected
+        assert duration - duration_after_vad >= 0, "non-negative timestamp expected"
         if not duration_after_vad:
             audio_chunks, chunks_metadata = [], []
 

@@ -1,0 +1,190 @@
+"""TEST INFRASTRUCTURE — differential fuzzing of the host logic against the REFERENCE's own code (build container
+only: needs /root/reference).  For each seed a random recording (random silences) and a random combination of
+transcribe() arguments is run through the reference's WhisperModel / BatchedInferencePipeline and through this
+repository's, both on oracle/scripted_backend.py; segments, words, info and the backend call logs must be equal.
+
+    python oracle/fuzz_host.py --seeds 200          # prints the first mismatch, exit code 1 on any
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    seconds = float(rng.uniform(8, 95))
+    silences, t = [], 0.0
+    while True:
+        t += float(rng.uniform(4, 30))
+        d = float(rng.uniform(0.5, 12))
+        if t + d >= seconds:
+            break
+        if rng.random() < 0.6:
+            silences.append((round(t, 2), round(t + d, 2)))
+        t += d
+    batched = bool(rng.random() < 0.4)
+    kw = dict(language=[None, "en", "zh", "de"][int(rng.integers(4))])
+    if rng.random() < 0.5:
+        kw["word_timestamps"] = True
+    if rng.random() < 0.3:
+        kw["multilingual"] = True
+    if rng.random() < 0.3:
+        kw["initial_prompt"] = ["hello world", " the test.", [260, 261]][int(rng.integers(3))]
+    if rng.random() < 0.3:
+        kw["hotwords"] = "whisper audio"
+    if rng.random() < 0.3:
+        kw["max_new_tokens"] = int(rng.integers(5, 120))
+    if rng.random() < 0.3:
+        kw["beam_size"] = int(rng.integers(1, 6))
+    if rng.random() < 0.2:
+        kw["suppress_tokens"] = [int(x) for x in rng.integers(0, 400, size=3)]
+    if batched:
+        if isinstance(kw.get("initial_prompt"), list):
+            kw["initial_prompt"] = "hello"       # token-id prompts in the batched path are an extension here (the
+                                                 # reference only takes a string there and raises TypeError otherwise)
+        kw["batch_size"] = int(rng.integers(1, 5))
+        kw["without_timestamps"] = bool(rng.random() < 0.5)
+        mode = rng.random()
+        if seconds < 30 and mode < 0.3:
+            kw["vad_filter"] = False
+        elif mode < 0.65:
+            kw["vad_filter"] = True
+            kw["vad_parameters"] = dict(min_silence_duration_ms=int(rng.integers(100, 1500)),
+                                        speech_pad_ms=int(rng.integers(0, 500)))
+        else:
+            cuts = sorted(set([0.0, seconds] + [round(float(x), 2) for x in rng.uniform(0, seconds, size=4)]))
+            clips = [dict(start=a, end=b) for a, b in zip(cuts[:-1], cuts[1:]) if 0.5 < b - a <= 30.0]
+            if not clips:
+                clips = [dict(start=0.0, end=min(seconds, 30.0))]
+            kw["clip_timestamps"] = clips
+    else:
+        kw["without_timestamps"] = bool(rng.random() < 0.25)
+        if rng.random() < 0.3:
+            kw["prefix"] = "the model"
+        if rng.random() < 0.4:
+            kw["condition_on_previous_text"] = False
+        if rng.random() < 0.4:
+            kw["temperature"] = [[0.0], [0.0, 0.4, 0.8], 0.0, [0.2, 0.6]][int(rng.integers(4))]
+        if rng.random() < 0.3:
+            kw["best_of"] = int(rng.integers(1, 5))
+        if rng.random() < 0.3:
+            kw["no_speech_threshold"] = [None, 0.3, 0.9][int(rng.integers(3))]
+        if rng.random() < 0.3:
+            kw["log_prob_threshold"] = [None, -0.5, -1.5][int(rng.integers(3))]
+        if rng.random() < 0.3:
+            kw["compression_ratio_threshold"] = [None, 1.5, 3.0][int(rng.integers(3))]
+        if rng.random() < 0.3:
+            kw["prompt_reset_on_temperature"] = float(rng.choice([0.1, 0.5, 0.9]))
+        if kw.get("word_timestamps") and rng.random() < 0.6:
+            kw["hallucination_silence_threshold"] = float(rng.choice([0.5, 1.0, 2.0]))
+        mode = rng.random()
+        if mode < 0.25:
+            kw["vad_filter"] = True
+            kw["vad_parameters"] = dict(min_silence_duration_ms=int(rng.integers(100, 2500)))
+        elif mode < 0.5:
+            pts = sorted(round(float(x), 1) for x in rng.uniform(0, seconds, size=int(rng.integers(1, 5))))
+            kw["clip_timestamps"] = pts if rng.random() < 0.5 else ",".join(str(p) for p in pts)
+        if rng.random() < 0.2:
+            kw["language_detection_segments"] = 2
+            kw["language_detection_threshold"] = 0.8
+    return dict(kind="batched" if batched else "sequential", audio=(1000 + seed, round(seconds, 2), tuple(silences)),
+                kwargs=kw)
+
+
+def run_reference(fw, cfg, hf_tok, case):
+    from gen_golden_host import jsonable, make_reference_model
+    from oracle import host_scenarios as hs
+    model = make_reference_model(fw, cfg, hf_tok)
+    audio = hs.synth_audio(*case["audio"])
+    kwargs = json.loads(json.dumps(case["kwargs"]))
+    if case["kind"] == "sequential":
+        segments, info = model.transcribe(audio, **kwargs)
+    else:
+        segments, info = fw.BatchedInferencePipeline(model).transcribe(audio, **kwargs)
+    segments = [jsonable(s) for s in segments]
+    return dict(segments=segments, language=info.language, language_probability=float(info.language_probability),
+                duration_after_vad=info.duration_after_vad, calls=jsonable(model.model.calls))
+
+
+def run_mine(cfg, hf_tok, case):
+    from faster_whisper_amd.transcribe import BatchedInferencePipeline
+    from oracle import host_scenarios as hs
+    from test_host_golden import _plain, make_model
+    model = make_model(cfg, hf_tok)
+    audio = hs.synth_audio(*case["audio"])
+    kwargs = json.loads(json.dumps(case["kwargs"]))
+    if kwargs.get("vad_filter"):
+        kwargs["vad_speech_probs"] = hs.speech_probs(np.pad(audio, (0, 512 - audio.shape[0] % 512)))
+    if case["kind"] == "sequential":
+        segments, info = model.transcribe(audio, **kwargs)
+    else:
+        segments, info = BatchedInferencePipeline(model).transcribe(audio, **kwargs)
+    segments = [_plain(s) for s in segments]
+    return dict(segments=segments, language=info.language, language_probability=float(info.language_probability),
+                duration_after_vad=info.duration_after_vad, calls=_plain(model.model.calls))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--start", type=int, default=0)
+    args = ap.parse_args()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden_host as gg
+    gg.install_stubs()
+    import faster_whisper as fw
+    import faster_whisper.feature_extractor  # noqa: F401
+    import faster_whisper.tokenizer as ref_tok
+    import faster_whisper.vad as ref_vad
+    from faster_whisper_amd import get_config
+    from oracle import host_scenarios as hs
+    from oracle import micro_tokenizer
+    from test_host_golden import _close
+    ref_tok._LANGUAGE_CODES = ("en", "zh", "de", "es")
+    ref_vad.get_vad_model = lambda: hs.speech_probs
+    cfg = get_config("micro")
+    hf_tok = micro_tokenizer.build()
+    bad = 0
+    stats = dict(segments=0, words=0, generate=0, align=0, errors_equal=0)
+    for seed in range(args.start, args.start + args.seeds):
+        case = random_case(seed)
+        try:
+            want = run_reference(fw, cfg, hf_tok, case)
+            ref_err = None
+        except Exception as e:      # the reference itself rejects some argument combinations: so must we
+            want, ref_err = None, type(e).__name__
+        try:
+            got = run_mine(cfg, hf_tok, case)
+            my_err = None
+        except Exception as e:
+            got, my_err = None, type(e).__name__
+        if ref_err or my_err:
+            if ref_err != my_err:
+                bad += 1
+                print(f"seed {seed}: reference raised {ref_err}, this repository {my_err}: {case}")
+            else:
+                stats["errors_equal"] += 1
+            continue
+        try:
+            _close(got, want, f"seed{seed}")
+        except AssertionError as e:
+            bad += 1
+            print(f"seed {seed} MISMATCH {str(e)[:400]}\n  case: {case}")
+            continue
+        stats["segments"] += len(want["segments"])
+        stats["words"] += sum(len(s["words"] or []) for s in want["segments"])
+        stats["generate"] += sum(1 for c in want["calls"] if c[0] == "generate")
+        stats["align"] += sum(1 for c in want["calls"] if c[0] == "align")
+    print(json.dumps(dict(seeds=args.seeds, mismatches=bad, **stats)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
