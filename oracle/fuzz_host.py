@@ -45,6 +45,25 @@ def random_case(seed):
         kw["beam_size"] = int(rng.integers(1, 6))
     if rng.random() < 0.2:
         kw["suppress_tokens"] = [int(x) for x in rng.integers(0, 400, size=3)]
+    if rng.random() < 0.15:
+        kw["suppress_tokens"] = [None, [], [-1, 7]][int(rng.integers(3))]
+    if rng.random() < 0.2:
+        kw["suppress_blank"] = False
+    if rng.random() < 0.2:
+        kw["task"] = "translate"
+    if rng.random() < 0.2:
+        kw["patience"] = float(rng.choice([0.5, 2.0]))
+        kw["length_penalty"] = float(rng.choice([0.0, 0.6, 2.0]))
+    if rng.random() < 0.2:
+        kw["repetition_penalty"] = 1.3
+        kw["no_repeat_ngram_size"] = int(rng.integers(0, 4))
+    if rng.random() < 0.15:
+        kw["chunk_length"] = int(rng.choice([10, 20, 25]))
+    if rng.random() < 0.2:
+        kw["max_initial_timestamp"] = float(rng.choice([0.0, 0.5, 2.0]))
+    if rng.random() < 0.15:
+        kw["prepend_punctuations"] = "\"'([{"
+        kw["append_punctuations"] = ".,!?)]}"
     if batched:
         if isinstance(kw.get("initial_prompt"), list):
             kw["initial_prompt"] = "hello"       # token-id prompts in the batched path are an extension here (the
