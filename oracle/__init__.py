@@ -14,7 +14,9 @@ Pinning status
     disk.  The restatement follows openai-whisper / CTranslate2 4.x published behaviour
      and is anchored on the reference's call sites
     (transcribe.py:222-236, :1433-1459, :1709-1715, :1823) and on cross-checks against the
-    installed `transformers` Whisper implementation: architecture (tests/test_oracle_arch.py),
+    installed `transformers` Whisper implementation: architecture and a whole greedy decode with
+    timestamps — tokens, score, no-speech probability — against a loop made of transformers' forward
+    and transformers' own logits processors (tests/test_oracle_arch.py),
     timestamp / suppress logits rules, median filter and DTW (tests/test_oracle_vs_hf_rules.py:
     identical on random inputs).  Beam-search bookkeeping and int8 conventions stay [CT2-ext].
   * host logic of the callers (prompts, seek loop, temperature fallback, word timestamps, VAD

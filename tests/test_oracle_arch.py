@@ -93,3 +93,54 @@ def test_oracle_matches_transformers_whisper():
             h = oracle.decoder_step(tokens[:, pos], pos, cache, ckv)
         step_logits = oracle.logits(h).numpy()
     assert np.abs(step_logits - logits[:, -1]).max() < 1e-4
+
+
+def test_greedy_decode_matches_a_loop_built_from_transformers_parts():
+    """oracle.generate (greedy, timestamps on: prompt forward, KV-cached steps, suppress / blank / timestamp rules,
+    log-softmax, score = cum / len) against a plain loop made of independent parts: transformers' Whisper forward +
+    transformers' own logits processors.  Same tokens, same cumulative log-probability, same no-speech probability."""
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=9, dtype=np.float32)
+    hf = _load_into_hf(cfg, w)
+    oracle = OracleWhisper(cfg, w, emulate_fp16=False)
+    rng = np.random.default_rng(4)
+    feats = rng.standard_normal((2, cfg.n_mels, 3000)).astype(np.float32) * 0.5
+    prompt = list(cfg.sot_sequence)                       # timestamps enabled
+    sup = sorted({cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe, 3, 4, 5})
+    n_new, mits = 14, 50
+
+    class G:
+        eos_token_id = cfg.eot
+        bos_token_id = cfg.eot
+        no_timestamps_token_id = cfg.no_timestamps
+        max_initial_timestamp_index = mits
+        _detect_timestamp_from_logprob = True
+    procs = [lp.SuppressTokensAtBeginLogitsProcessor(list(cfg.suppress_begin), begin_index=len(prompt)),
+             lp.SuppressTokensLogitsProcessor(sup),
+             lp.WhisperTimeStampLogitsProcessor(G(), begin_index=len(prompt))]
+    enc = oracle.encode(feats)
+    got = oracle.generate(enc, [prompt] * 2, beam_size=1, max_length=len(prompt) + n_new, suppress_tokens=sup,
+                          suppress_blank=True, max_initial_timestamp_index=mits, length_penalty=1.0)
+    with torch.no_grad():
+        for b in range(2):
+            ids = torch.tensor([prompt])
+            cum, toks, no_speech = 0.0, [], None
+            for step in range(n_new):
+                logits = hf(input_features=torch.from_numpy(feats[b:b + 1]), decoder_input_ids=ids).logits[0]
+                if no_speech is None:   # softmax at the <|startoftranscript|> position (SURVEY.md A.3)
+                    no_speech = float(torch.softmax(logits[0].float(), -1)[cfg.no_speech])
+                scores = logits[-1:].float().clone()
+                for p in procs:
+                    scores = p(ids, scores)
+                logp = torch.log_softmax(scores, dim=-1)[0]
+                t = int(torch.argmax(logp))
+                cum += float(logp[t])
+                if t == cfg.eot:
+                    break
+                toks.append(t)
+                ids = torch.cat([ids, torch.tensor([[t]])], dim=1)
+            g = got[b]
+            assert g.sequences_ids[0] == toks, (b, g.sequences_ids[0], toks)
+            assert abs(g.scores[0] - cum / max(1, len(toks))) < 1e-4 * max(1.0, abs(cum))
+            assert abs(g.no_speech_prob - no_speech) < 1e-5
