@@ -34,6 +34,8 @@ pmc_pass sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VA
 
 cd "$R"
 timeout 300 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+# the opt-in end-to-end pipeline number (first hardware run: kept apart from the bench line above)
+timeout 200 python bench.py --pipeline --no-cpu-baseline --no-profile-pass --steps 8 > "$OUT/bench_pipeline.json" 2> "$OUT/bench_pipeline.err"
 
 cd /tmp
 FWAMD_NO_GRAPH=1 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_kt" -o kt -- \
