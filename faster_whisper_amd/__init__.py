@@ -20,4 +20,11 @@ def __getattr__(name):
                 "TranscriptionOptions", "FeatureExtractor", "Tokenizer"):
         from . import transcribe as _t
         return getattr(_t, name)
+    # the rest of the reference's top level (faster_whisper/__init__.py)
+    if name == "decode_audio":
+        from .audio import decode_audio
+        return decode_audio
+    if name in ("format_timestamp", "available_models"):
+        from . import utils as _u
+        return getattr(_u, name)
     raise AttributeError(name)
