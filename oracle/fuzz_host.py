@@ -150,10 +150,52 @@ def run_mine(cfg, hf_tok, case):
                 duration_after_vad=info.duration_after_vad, calls=_plain(model.model.calls))
 
 
+def fuzz_units(hf_tok, cfg, n_cases, seed):
+    """random token sequences (raw bytes incl. partial UTF-8, merges, special tokens, timestamps): decode,
+    decode_with_timestamps, split_to_word_tokens and merge_punctuations of both implementations must agree"""
+    import faster_whisper.tokenizer as ref_tok
+    from faster_whisper.transcribe import merge_punctuations as ref_merge
+    from faster_whisper_amd import words as my_words
+    from faster_whisper_amd.transcribe import Tokenizer
+    rng = np.random.default_rng(seed)
+    sample = hf_tok.encode(" hello world, 世界 café (test) \"a\" - x!", add_special_tokens=False).ids
+    pre, app = "\"'“¿([{-", "\"'.。,，!！?？:：”)]}、"
+    bad = 0
+    for trial in range(n_cases):
+        lang = ("en", "zh", "de")[trial % 3]
+        ref = ref_tok.Tokenizer(hf_tok, True, task="transcribe", language=lang)
+        mine = Tokenizer(hf_tok, cfg, True, task="transcribe", language=lang)
+        ids = []
+        for _ in range(int(rng.integers(0, 25))):
+            r = rng.random()
+            if r < 0.55:
+                ids.append(int(rng.integers(0, 400)))
+            elif r < 0.8:
+                ids.append(int(rng.choice(sample)))
+            elif r < 0.9:
+                ids.append(int(cfg.timestamp_begin + rng.integers(0, 1500)))
+            else:
+                ids.append(int(rng.integers(cfg.eot, cfg.timestamp_begin)))
+        ids.append(cfg.eot)
+        a, b = ref.split_to_word_tokens(list(ids)), mine.split_to_word_tokens(list(ids))
+        al = [dict(word=w, tokens=list(t)) for w, t in zip(*a)]
+        bl = [dict(word=w, tokens=list(t)) for w, t in zip(*b)]
+        ref_merge(al, pre, app)
+        my_words.merge_punctuations(bl, pre, app)
+        ok = (a == b and al == bl and ref.decode(ids) == mine.decode(ids)
+              and ref.decode_with_timestamps(ids) == mine.decode_with_timestamps(ids))
+        if not ok:
+            bad += 1
+            if bad <= 3:
+                print(f"unit mismatch ({lang}): ids={ids}\n  reference {a}\n  here      {b}")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--start", type=int, default=0)
+    ap.add_argument("--units", type=int, default=0, help="also fuzz N random token sequences through the tokenizer")
     args = ap.parse_args()
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gen_golden_host as gg
@@ -201,8 +243,9 @@ def main():
         stats["words"] += sum(len(s["words"] or []) for s in want["segments"])
         stats["generate"] += sum(1 for c in want["calls"] if c[0] == "generate")
         stats["align"] += sum(1 for c in want["calls"] if c[0] == "align")
-    print(json.dumps(dict(seeds=args.seeds, mismatches=bad, **stats)))
-    return 1 if bad else 0
+    unit_bad = fuzz_units(hf_tok, cfg, args.units, args.start) if args.units else 0
+    print(json.dumps(dict(seeds=args.seeds, mismatches=bad, units=args.units, unit_mismatches=unit_bad, **stats)))
+    return 1 if (bad or unit_bad) else 0
 
 
 if __name__ == "__main__":
