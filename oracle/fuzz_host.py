@@ -191,8 +191,66 @@ def fuzz_units(hf_tok, cfg, n_cases, seed):
     return bad
 
 
+def fuzz_vad(n_cases, seed):
+    """random probability tracks x random VadOptions: speech spans, chunk collection and the timestamp map of both
+    implementations must agree exactly"""
+    import faster_whisper.vad as rv
+    from faster_whisper_amd import vad as mv
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for trial in range(n_cases):
+        n = int(rng.integers(1, 400))
+        kind = int(rng.integers(4))
+        if kind == 0:
+            p = rng.random(n)
+        elif kind == 1:
+            p = np.clip(0.5 + np.cumsum(rng.normal(0, 0.15, n)) * 0.4, 0, 1)
+        elif kind == 2:
+            p = (rng.random(n) < 0.5).astype(float) * rng.uniform(0.4, 1.0) + 0.01
+        else:
+            p = np.full(n, 0.02)
+            for _ in range(int(rng.integers(1, 6))):
+                a = int(rng.integers(0, n))
+                p[a:min(n, a + int(rng.integers(1, 80)))] = rng.uniform(0.3, 1.0)
+        n_audio = max(1, n * 512 - int(rng.integers(1, 512)) if rng.random() < 0.7 else (n - 1) * 512 if n > 1 else 300)
+        p = np.resize(p, n_audio // 512 + 1)          # one probability per window of the padded audio
+        opts = dict(threshold=float(rng.choice([0.3, 0.5, 0.7])))
+        if rng.random() < 0.4:
+            opts["neg_threshold"] = float(rng.choice([0.05, 0.2, 0.35]))
+        if rng.random() < 0.5:
+            opts["min_speech_duration_ms"] = int(rng.choice([0, 100, 250, 1000]))
+        if rng.random() < 0.5:
+            opts["max_speech_duration_s"] = float(rng.choice([1.0, 3.0, 8.0, 30.0]))
+        if rng.random() < 0.7:
+            opts["min_silence_duration_ms"] = int(rng.choice([0, 50, 100, 500, 2000]))
+        if rng.random() < 0.7:
+            opts["speech_pad_ms"] = int(rng.choice([0, 30, 100, 400]))
+        rv.get_vad_model = lambda p=p: (lambda padded: p)
+        audio = np.zeros(n_audio, np.float32)
+        a = rv.get_speech_timestamps(audio, rv.VadOptions(**opts))
+        b = mv.get_speech_timestamps(audio, mv.VadOptions(**opts), speech_probs=p)
+        ok = a == b
+        if ok and a:
+            idx = np.arange(n_audio, dtype=np.float32)
+            for md in (1.0, 5.0, float("inf")):
+                ca, ma = rv.collect_chunks(idx, [dict(s) for s in a], max_duration=md)
+                cb, mb = mv.collect_chunks(idx, [dict(s) for s in b], max_duration=md)
+                ok = ok and ma == mb and len(ca) == len(cb) and all(np.array_equal(x, y) for x, y in zip(ca, cb))
+            ta, tb = rv.SpeechTimestampsMap(a, 16000), mv.SpeechTimestampsMap(b, 16000)
+            for q in rng.uniform(0, max(0.01, sum(s["end"] - s["start"] for s in a) / 16000), size=5):
+                ok = ok and ta.get_original_time(q) == tb.get_original_time(q) \
+                    and ta.get_original_time(q, is_end=True) == tb.get_original_time(q, is_end=True) \
+                    and ta.get_chunk_index(q) == tb.get_chunk_index(q)
+        if not ok:
+            bad += 1
+            if bad <= 3:
+                print(f"vad mismatch: {opts} n_audio={n_audio}\n  reference {a[:4]}\n  here      {b[:4]}")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--vad", type=int, default=0, help="also fuzz N random probability tracks through the VAD logic")
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--start", type=int, default=0)
     ap.add_argument("--units", type=int, default=0, help="also fuzz N random token sequences through the tokenizer")
@@ -244,8 +302,11 @@ def main():
         stats["generate"] += sum(1 for c in want["calls"] if c[0] == "generate")
         stats["align"] += sum(1 for c in want["calls"] if c[0] == "align")
     unit_bad = fuzz_units(hf_tok, cfg, args.units, args.start) if args.units else 0
-    print(json.dumps(dict(seeds=args.seeds, mismatches=bad, units=args.units, unit_mismatches=unit_bad, **stats)))
-    return 1 if (bad or unit_bad) else 0
+    vad_bad = fuzz_vad(args.vad, args.start) if args.vad else 0
+    ref_vad.get_vad_model = lambda: hs.speech_probs
+    print(json.dumps(dict(seeds=args.seeds, mismatches=bad, units=args.units, unit_mismatches=unit_bad, vad=args.vad,
+                          vad_mismatches=vad_bad, **stats)))
+    return 1 if (bad or unit_bad or vad_bad) else 0
 
 
 if __name__ == "__main__":
