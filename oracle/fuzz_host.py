@@ -248,8 +248,30 @@ def fuzz_vad(n_cases, seed):
     return bad
 
 
+def fuzz_logmel(n_cases, seed):
+    """random lengths / amplitudes: oracle/logmel.py must stay BIT-identical to the reference's FeatureExtractor"""
+    import faster_whisper.feature_extractor as ref_fe
+    from oracle import logmel as olm
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for trial in range(n_cases):
+        n_mels = (80, 128)[trial % 2]
+        fe = ref_fe.FeatureExtractor(feature_size=n_mels)
+        length = int(rng.choice([0, 1, 159, 160, 161, 399, 400, 401, 1000, 16000, 48000, int(rng.integers(1, 200000))]))
+        x = (rng.standard_normal(length) * float(rng.choice([1e-4, 0.01, 0.3, 1.0]))).astype(np.float32)
+        if trial % 7 == 0:
+            x[:] = 0
+        a, b = fe(x), olm.log_mel_full(x, n_mels)
+        if a.shape != b.shape or not np.array_equal(a, b):
+            bad += 1
+            if bad <= 3:
+                print(f"log-mel mismatch: n_mels={n_mels} length={length} shapes {a.shape} {b.shape}")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--logmel", type=int, default=0, help="also fuzz N random waveforms through the log-mel oracle")
     ap.add_argument("--vad", type=int, default=0, help="also fuzz N random probability tracks through the VAD logic")
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--start", type=int, default=0)
@@ -304,9 +326,10 @@ def main():
     unit_bad = fuzz_units(hf_tok, cfg, args.units, args.start) if args.units else 0
     vad_bad = fuzz_vad(args.vad, args.start) if args.vad else 0
     ref_vad.get_vad_model = lambda: hs.speech_probs
+    mel_bad = fuzz_logmel(args.logmel, args.start) if args.logmel else 0
     print(json.dumps(dict(seeds=args.seeds, mismatches=bad, units=args.units, unit_mismatches=unit_bad, vad=args.vad,
-                          vad_mismatches=vad_bad, **stats)))
-    return 1 if (bad or unit_bad or vad_bad) else 0
+                          vad_mismatches=vad_bad, logmel=args.logmel, logmel_mismatches=mel_bad, **stats)))
+    return 1 if (bad or unit_bad or vad_bad or mel_bad) else 0
 
 
 if __name__ == "__main__":

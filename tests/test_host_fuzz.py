@@ -15,10 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/faster_whisper"), reason="reference checkout not on this box")
 def test_fuzz_against_reference_host_code():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "fuzz_host.py"), "--seeds", "40", "--start", "1000", "--units", "600", "--vad", "400"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "fuzz_host.py"), "--seeds", "40", "--start", "1000", "--units", "600", "--vad", "400", "--logmel", "24"],
                        capture_output=True, text=True, timeout=900)
     last = r.stdout.strip().splitlines()[-1]
     stats = json.loads(last)
     assert r.returncode == 0 and stats["mismatches"] == 0 and stats["unit_mismatches"] == 0 \
-        and stats["vad_mismatches"] == 0, r.stdout[-3000:]
+        and stats["vad_mismatches"] == 0 and stats["logmel_mismatches"] == 0, r.stdout[-3000:]
     assert stats["segments"] > 100 and stats["generate"] > 100
