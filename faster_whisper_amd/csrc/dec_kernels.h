@@ -43,6 +43,9 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act);
+int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq,
+                            const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
+                            int R, int N, int K, int act);
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
 void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
                            const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok);

@@ -539,6 +539,104 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 }
 
 // ------------------------------------------------------------------------------------
+// int8 form of the fragment-major skinny GEMM (int8_float16; experiment, FWAMD_DEC_GEMM_I8=frag at pack time —
+// written after round 1's GPU budget was spent: compiles, not yet run).  Same structure as
+// dec_gemm_frag_kernel with v_mfma_i32_16x16x64_i8: a 16-byte fragment holds 16 int8 (k-step = 64), weights are
+// permuted at pack time, activations are written fragment-major by quant_rows_kernel(frag = 1); the epilogue
+// de-quantises with the per-row activation scale and the per-row weight scale.  Output fp16 row-major.
+// ------------------------------------------------------------------------------------
+template <int WAVES, int RT, int NT>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_i8_kernel(
+    const int8_t* __restrict__ xq, const float* __restrict__ x_scale, const int8_t* __restrict__ Wq,
+    const float* __restrict__ w_scale, const half_t* __restrict__ bias, const half_t* __restrict__ res, int ldr,
+    half_t* __restrict__ out, int ldo, int R, int N, int K, int act) {
+  __shared__ int red[WAVES][RT * NT][64][4];
+  constexpr int CH = 20 / (RT + NT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
+  const int n_rt = (R + 15) >> 4;
+  const int KS = K >> 6;
+  const int per = (KS + WAVES - 1) / WAVES;
+  const int ks0 = wave * per;
+  int nks = KS - ks0;
+  if (nks > per) nks = per;
+  intx4 acc[RT][NT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = intx4{0, 0, 0, 0};
+  if (nks > 0) {
+    const intx4* wp[NT];
+    const intx4* xp[RT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+      wp[b] = reinterpret_cast<const intx4*>(Wq) + ((size_t)(ct0 + b) * KS + ks0) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      int rt = rt0 + a;
+      if (rt > n_rt - 1) rt = n_rt - 1;
+      xp[a] = reinterpret_cast<const intx4*>(xq) + ((size_t)rt * KS + ks0) * 64 + lane;
+    }
+    for (int c = 0; c < nks; c += CH) {
+      intx4 wv[NT][CH], xv[RT][CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int jj = (c + j < nks) ? c + j : nks - 1;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) wv[b][j] = wp[b][(size_t)jj * 64];
+#pragma unroll
+        for (int a = 0; a < RT; ++a) xv[a][j] = xp[a][(size_t)jj * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if (c + j < nks) {
+#pragma unroll
+          for (int a = 0; a < RT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[b][j], xv[a][j], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][a * NT + b][lane][e] = acc[a][b][e];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < RT; ++a) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if ((a * NT + b) % WAVES != wave) continue;
+      const int row = (rt0 + a) * 16 + i;
+      if (row >= R) continue;
+      int v[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += red[w][a * NT + b][lane][e];      // exact: integer accumulation
+      const float sx = x_scale[row];
+      const int n = (ct0 + b) * 16 + 4 * g;
+      half4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float tv = (float)v[e] * sx * w_scale[n + e];
+        if (bias) tv += (float)bias[n + e];
+        if (act == 1) tv = gelu_erf(tv);
+        if (res) tv += (float)res[(size_t)row * ldr + n + e];
+        o[e] = (half_t)tv;
+      }
+      *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Row-loop form of the fragment-major skinny GEMM (experiment, FWAMD_FRAG_ROWLOOP=1; K <= 1280):
 // one workgroup = NT column tiles x ALL row tiles.  Its weight fragments (NT x 10 k-steps per wave) are loaded
 // ONCE and stay in registers while the row tiles are walked two at a time, so a weight byte crosses the fabric
@@ -1538,6 +1636,19 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
   else if (env_nt == 2) { if (lnf) FG(true, 1, 2); else FG(false, 1, 2); }
   else { if (lnf) FG(true, 1, 1); else FG(false, 1, 1); }
 #undef FG
+  return 0;
+}
+
+// int8 fragment-major skinny GEMM (see dec_gemm_frag_i8_kernel); xq / Wq fragment-major, out row-major fp16
+int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq,
+                            const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
+                            int R, int N, int K, int act) {
+  if (K % 64 != 0 || N % 32 != 0 || R < 1 || R > 80 || !x_scale || !w_scale) return -1;
+  const dim3 grid(N / 32, ((R + 15) / 16 + 1) / 2);
+  if (K >= 2560)
+    dec_gemm_frag_i8_kernel<8, 2, 2><<<grid, 512, 0, st>>>(xq, x_scale, Wq, w_scale, bias, res, ldr, out, ldo, R, N, K, act);
+  else
+    dec_gemm_frag_i8_kernel<4, 2, 2><<<grid, 256, 0, st>>>(xq, x_scale, Wq, w_scale, bias, res, ldr, out, ldo, R, N, K, act);
   return 0;
 }
 

@@ -97,8 +97,9 @@ int gen_workspace_create(Model* m) {
   A(g->sup_mask, (size_t)c.n_vocab);
   A(g->zero_done, Rg);
   if (m->compute_type == FW_COMPUTE_INT8_FLOAT16) {
-    A(g->xq, Rg * 4 * d);
+    A(g->xq, (Rg + 15) / 16 * 16 * 4 * d);   // whole 16-row tiles (fragment-major form)
     A(g->xs, Rg);
+    FW_HIP(hipMemset(g->xq, 0, (Rg + 15) / 16 * 16 * 4 * d));
   }
   if (m->dec_frag) {
     const size_t R16 = (Rg + 15) / 16 * 16;   // whole 16-row tiles
@@ -209,6 +210,11 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   // int8_float16 (K25): the row quantiser (fused with the LayerNorm where one feeds the linear) runs as its
   // own tiny kernel, then the int8 skinny GEMM de-quantises in its epilogue
   auto lin_q = [&](const half_t* xin, const LNW* ln, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
+    if (m->dec_frag_i8) {   // opt-in: fragment-major int8 operands, register-streaming kernel
+      fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K, 1);
+      return fwd::launch_dec_gemm_frag_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K,
+                                          act);
+    }
     fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K);
     return fwd::launch_dec_gemm_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K, act,
                                    false);

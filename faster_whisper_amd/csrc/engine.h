@@ -98,6 +98,7 @@ struct Model {
   fw_config cfg{};
   int compute_type = 0;
   bool dec_frag = false;   // decoder linears + their inputs are stored MFMA-fragment-major (dec_gemm_frag_kernel)
+  bool dec_frag_i8 = false;   // same for the int8 decoder linears (dec_gemm_frag_i8_kernel), opt-in experiment
   int device = 0;
   int max_batch = 0, max_beam = 0;
   hipStream_t stream = nullptr;

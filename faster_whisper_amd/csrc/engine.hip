@@ -381,6 +381,40 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     }
   }
 
+  // int8 fragment-major decoder linears (dec_gemm_frag_i8_kernel; experiment, opt-in at pack time with
+  // FWAMD_DEC_GEMM_I8=frag): Wq[n][k] moves to ((n/16 * K/64 + k/64) * 64 + 16*((k/16)%4) + n%16) * 16 + k%16
+  bool frag_i8 = false;
+  if (i8) {
+    const char* e8 = getenv("FWAMD_DEC_GEMM_I8");
+    frag_i8 = e8 && e8[0] == 'f';
+  }
+  if (frag_i8) {
+    for (PackItem& it : items) {
+      const std::string& nm = it.name;
+      if (nm.compare(0, 4, "dec.") != 0 || it.ndim != 2 || it.dtype != 2) continue;
+      auto ends = [&](const char* suf) {
+        const size_t n = strlen(suf);
+        return nm.size() >= n && nm.compare(nm.size() - n, n, suf) == 0;
+      };
+      if (!(ends("self.qkv.wq") || ends("self.out.wq") || ends("cross.q.wq") || ends("cross.out.wq") ||
+            ends("ffn1.wq") || ends("ffn2.wq")))
+        continue;
+      const int64_t N = it.dims[0], K = it.dims[1];
+      if (N % 16 || K % 64) {
+        set_error("int8 fragment-major packing needs N %% 16 == 0 and K %% 64 == 0 (%s is %lld x %lld)", nm.c_str(),
+                  (long long)N, (long long)K);
+        return FW_EINVAL;
+      }
+      std::vector<int8_t> src;
+      src.swap(it.qdata);
+      it.qdata.resize(src.size());
+      const int64_t KS = K / 64;
+      for (int64_t n = 0; n < N; ++n)
+        for (int64_t k = 0; k < K; ++k)
+          it.qdata[(((n >> 4) * KS + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (n & 15)) * 16 + (k & 15)] = src[n * K + k];
+    }
+  }
+
   const int64_t hdr = (int64_t)sizeof(BlobHeader) + (int64_t)items.size() * sizeof(BlobEntry);
   int64_t off = (hdr + 255) / 256 * 256;
   std::vector<BlobEntry> entries(items.size());
@@ -403,7 +437,7 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   h.n_tensors = (int32_t)items.size();
   h.total_bytes = off;
   h.compute_type = compute_type;
-  h.reserved = frag ? 1 : 0;   // bit 0: decoder linears are fragment-major
+  h.reserved = (frag ? 1 : 0) | (frag_i8 ? 2 : 0);   // bit 0 / 1: fp16 / int8 decoder linears are fragment-major
   h.cfg = *cfg;
   memcpy(blob.data(), &h, sizeof(h));
   memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
@@ -638,6 +672,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   m->cfg = h.cfg;
   m->compute_type = h.compute_type;
   m->dec_frag = (h.reserved & 1) != 0;
+  m->dec_frag_i8 = (h.reserved & 2) != 0;
   m->device = device;
   m->max_batch = max_batch;
   m->max_beam = max_beam;

@@ -35,8 +35,9 @@ int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
 void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d);
 // per-row dynamic int8 quantisation (absmax / 127), optionally preceded by LayerNorm (g != null):
 // xq[r][:] = rint(y * 127 / absmax(y)), scale[r] = absmax / 127 with y = LN(x[r]) rounded to fp16, or x[r]
+// frag != 0: xq is written MFMA-fragment-major for the int8 register-streaming skinny GEMM (needs d % 64 == 0)
 void launch_quant_rows(hipStream_t st, const half_t* x, int64_t ldx, const half_t* g, const half_t* b, int8_t* xq,
-                       float* scale, int rows, int d);
+                       float* scale, int rows, int d, int frag = 0);
 void launch_f32_to_f16(hipStream_t st, const float* x, half_t* y, int64_t n);
 void launch_f16_to_f32(hipStream_t st, const half_t* x, float* y, int64_t n);
 

@@ -57,12 +57,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 __global__ __launch_bounds__(256) void quant_rows_kernel(const half_t* __restrict__ x, int64_t ldx,
                                                          const half_t* __restrict__ g, const half_t* __restrict__ b,
                                                          int8_t* __restrict__ xq, float* __restrict__ scale, int rows,
-                                                         int d) {
+                                                         int d, int frag) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const half2_t* xr = reinterpret_cast<const half2_t*>(x + (size_t)row * ldx);
   char2* qr = reinterpret_cast<char2*>(xq + (size_t)row * d);
+  // frag != 0: int8 MFMA-fragment-major destination (dec_gemm_frag_i8_kernel): element (row, k) lives at byte
+  // ((row/16 * d/64 + k/64) * 64 + 16*((k/16)%4) + row%16) * 16 + k%16; pair index p = k/2 stays contiguous
+  auto dst = [&](int p) -> char2* {
+    if (!frag) return qr + p;
+    const int k = 2 * p;
+    const size_t off = ((size_t)((row >> 4) * (d >> 6) + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (row & 15)) * 16 + (k & 15);
+    return reinterpret_cast<char2*>(xq + off);
+  };
   const int nv = d >> 7;  // half2 per lane
   if (g) {
     float v0[LN_MAXV], v1[LN_MAXV];
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const half_t* __restric
         char2 o;
         o.x = (signed char)__float2int_rn(v0[i] * inv);
         o.y = (signed char)__float2int_rn(v1[i] * inv);
-        qr[i * 64 + lane] = o;
+        *dst(i * 64 + lane) = o;
       }
   } else {
     float amax = 0.f;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const half_t* __restric
       char2 o;
       o.x = (signed char)__float2int_rn((float)h[0] * inv);
       o.y = (signed char)__float2int_rn((float)h[1] * inv);
-      qr[i] = o;
+      *dst(i) = o;
     }
   }
 }
@@ -145,8 +153,8 @@ static int grid_for(int64_t n) {
   return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 void launch_quant_rows(hipStream_t st, const half_t* x, int64_t ldx, const half_t* g, const half_t* b, int8_t* xq,
-                       float* scale, int rows, int d) {
-  quant_rows_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, ldx, g, b, xq, scale, rows, d);
+                       float* scale, int rows, int d, int frag) {
+  quant_rows_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, ldx, g, b, xq, scale, rows, d, frag);
 }
 void launch_f32_to_f16(hipStream_t st, const float* x, half_t* y, int64_t n) {
   f32_to_f16_kernel<<<grid_for(n), 256, 0, st>>>(x, y, n);

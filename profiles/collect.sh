@@ -54,3 +54,11 @@ cut -c1-600 "$OUT/bench.json"
 FWAMD_TEST_UNVALIDATED=1 timeout 240 python -m pytest tests/test_gpu_vad.py tests/test_gpu_full_size.py -q -s 2>&1 \
     | tail -15 > "$OUT/unvalidated_tests.log"
 cat "$OUT/unvalidated_tests.log"
+# int8 fragment-major decoder GEMM (opt-in at pack time): parity first, then speed against the LDS form
+FWAMD_DEC_GEMM_I8=frag timeout 200 python -m pytest tests/test_gpu_int8.py -q 2>&1 | tail -3 > "$OUT/int8_frag_tests.log"
+cat "$OUT/int8_frag_tests.log"
+for s in "A=0" "FWAMD_DEC_GEMM_I8=frag"; do
+  timeout 150 env $s python profiles/sweep.py --compute-type int8_float16 --workers 1,8 --tag "int8 $s" \
+      >> "$OUT/sweep_int8.jsonl" 2>> "$OUT/sweep.err"
+done
+cat "$OUT/sweep_int8.jsonl"

@@ -36,7 +36,8 @@ def main():
 
     cfg = get_config(args.model)
     # the decoder weight layout is decided at pack time (FWAMD_DEC_GEMM), so it is part of the cache key
-    cache = f"/tmp/fwamd_blob_{args.model}_{args.compute_type}_{os.environ.get('FWAMD_DEC_GEMM', 'default')}.npy"
+    cache = (f"/tmp/fwamd_blob_{args.model}_{args.compute_type}_{os.environ.get('FWAMD_DEC_GEMM', 'default')}"
+             f"_{os.environ.get('FWAMD_DEC_GEMM_I8', 'default')}.npy")
     t0 = time.time()
     if os.path.exists(cache):
         blob = np.load(cache, mmap_mode="r")

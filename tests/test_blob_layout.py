@@ -56,3 +56,34 @@ def test_row_major_when_lds_form_is_selected(monkeypatch):
     monkeypatch.setenv("FWAMD_DEC_GEMM", "frag")
     h8, _ = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_INT8_FLOAT16))
     assert (h8.reserved & 1) == 0
+
+
+def test_int8_fragment_major_is_opt_in(monkeypatch):
+    """FWAMD_DEC_GEMM_I8=frag (experiment): int8 decoder weights permuted for v_mfma_i32_16x16x64_i8 — element
+    (n, k) at ((n/16 * K/64 + k/64) * 64 + 16*((k/16)%4) + n%16) * 16 + k%16 — flagged in header bit 1"""
+    from oracle.whisper import OracleWhisper
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=6)
+    monkeypatch.delenv("FWAMD_DEC_GEMM_I8", raising=False)
+    h0, t0 = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_INT8_FLOAT16))
+    assert (h0.reserved & 2) == 0
+    monkeypatch.setenv("FWAMD_DEC_GEMM_I8", "frag")
+    h1, t1 = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_INT8_FLOAT16))
+    assert (h1.reserved & 2) == 2 and (h1.reserved & 1) == 0
+    o = OracleWhisper(cfg, w, int8=True)
+    for name in ("dec.0.self.qkv", "dec.1.ffn2", "dec.0.cross.out"):
+        wq = o.q[name + ".w"][0].numpy().astype(np.int8)
+        n_rows, k_cols = wq.shape
+        n, k = np.meshgrid(np.arange(n_rows), np.arange(k_cols), indexing="ij")
+        off = (((n >> 4) * (k_cols // 64) + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (n & 15)) * 16 + (k & 15)
+        want = np.empty(n_rows * k_cols, np.int8)
+        want[off.reshape(-1)] = wq.reshape(-1)
+        assert np.array_equal(t1[name + ".wq"].reshape(-1), want), name
+        assert np.array_equal(t0[name + ".wq"], wq)                       # default: row-major
+        assert np.array_equal(t1[name + ".ws"], t0[name + ".ws"])
+    # encoder, cross-K/V and logits weights are not touched
+    for name in ("enc.0.ffn1.wq", "dec.0.cross.kv.wq", "dec.logits.wq"):
+        assert np.array_equal(t1[name], t0[name])
+    # fp16 packing ignores the int8 knob
+    h16, _ = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_FLOAT16))
+    assert (h16.reserved & 2) == 0
