@@ -1631,9 +1631,15 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
     return 0;
   }
 #define FG(L, A, B) frag_go<L, A, B>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
-  if (env_rt == 2 && env_nt == 2) { if (lnf) FG(true, 2, 2); else FG(false, 2, 2); }
-  else if (env_rt == 2) { if (lnf) FG(true, 2, 1); else FG(false, 2, 1); }
-  else if (env_nt == 2) { if (lnf) FG(true, 1, 2); else FG(false, 1, 2); }
+  // the long-K linear (ffn2, K = 4d) walks its k-steps in several chunks of 20/(RT+NT): its tile shape can be set
+  // apart (FWAMD_FRAG_LONGK_RT / _NT = 1 | 2, default: same as the others) — experiment knob
+  static const int lk_rt = [] { const char* e = getenv("FWAMD_FRAG_LONGK_RT"); return e ? (e[0] == '1' ? 1 : 2) : 0; }();
+  static const int lk_nt = [] { const char* e = getenv("FWAMD_FRAG_LONGK_NT"); return e ? (e[0] == '1' ? 1 : 2) : 0; }();
+  const int use_rt = (K >= 2560 && lk_rt) ? lk_rt : env_rt;
+  const int use_nt = (K >= 2560 && lk_nt) ? lk_nt : env_nt;
+  if (use_rt == 2 && use_nt == 2) { if (lnf) FG(true, 2, 2); else FG(false, 2, 2); }
+  else if (use_rt == 2) { if (lnf) FG(true, 2, 1); else FG(false, 2, 1); }
+  else if (use_nt == 2) { if (lnf) FG(true, 1, 2); else FG(false, 1, 2); }
   else { if (lnf) FG(true, 1, 1); else FG(false, 1, 1); }
 #undef FG
   return 0;

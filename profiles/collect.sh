@@ -44,7 +44,7 @@ f=$(find "$OUT/prof_kt" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp 
 rm -rf "$OUT/prof_kt"
 
 cd "$R"
-SWEEPS=("A=0" "FWAMD_FRAG_ROWLOOP=1" "FWAMD_FRAG_RT=1 FWAMD_FRAG_NT=1" "FWAMD_FRAG_WAVES=8" "FWAMD_CA_WAVES=4")
+SWEEPS=("A=0" "FWAMD_FRAG_ROWLOOP=1" "FWAMD_FRAG_LONGK_RT=1 FWAMD_FRAG_LONGK_NT=1" "FWAMD_FRAG_LONGK_RT=2 FWAMD_FRAG_LONGK_NT=1" "FWAMD_FRAG_RT=1 FWAMD_FRAG_NT=1" "FWAMD_FRAG_WAVES=8" "FWAMD_CA_WAVES=4")
 for s in "${SWEEPS[@]}"; do
   timeout 120 env $s python profiles/sweep.py --workers 1,8 --tag "$s" >> "$OUT/sweep.jsonl" 2>> "$OUT/sweep.err"
 done
