@@ -19,6 +19,14 @@ mkdir -p "$OUT"
 export FWAMD_BLOB_CACHE=/tmp/fwamd_blob_fp16.npy
 BENCH_PROF="python $R/bench.py --steps 1 --warmup 1 --workers 1 --no-cpu-baseline --no-profile-pass"
 
+cd "$R"
+# code written after round 1's GPU budget was spent: run it under a hard timeout, separately from the regular suite
+FWAMD_TEST_UNVALIDATED=1 timeout 240 python -m pytest tests/test_gpu_vad.py tests/test_gpu_full_size.py -q -s 2>&1 \
+    | tail -15 > "$OUT/unvalidated_tests.log"
+cat "$OUT/unvalidated_tests.log"
+# int8 fragment-major decoder GEMM (opt-in at pack time): parity first, then speed against the LDS form
+FWAMD_DEC_GEMM_I8=frag timeout 200 python -m pytest tests/test_gpu_int8.py -q 2>&1 | tail -3 > "$OUT/int8_frag_tests.log"
+cat "$OUT/int8_frag_tests.log"
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # name, counters...
   local name=$1; shift
@@ -44,19 +52,12 @@ f=$(find "$OUT/prof_kt" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp 
 rm -rf "$OUT/prof_kt"
 
 cd "$R"
-SWEEPS=("A=0" "FWAMD_FRAG_ROWLOOP=1" "FWAMD_FRAG_LONGK_RT=1 FWAMD_FRAG_LONGK_NT=1" "FWAMD_FRAG_LONGK_RT=2 FWAMD_FRAG_LONGK_NT=1" "FWAMD_FRAG_RT=1 FWAMD_FRAG_NT=1" "FWAMD_FRAG_WAVES=8" "FWAMD_CA_WAVES=4")
+SWEEPS=("A=0" "FWAMD_FRAG_ROWLOOP=1" "FWAMD_FRAG_LONGK_RT=1 FWAMD_FRAG_LONGK_NT=1")
 for s in "${SWEEPS[@]}"; do
   timeout 120 env $s python profiles/sweep.py --workers 1,8 --tag "$s" >> "$OUT/sweep.jsonl" 2>> "$OUT/sweep.err"
 done
 cat "$OUT/sweep.jsonl"
 cut -c1-600 "$OUT/bench.json"
-# code written after round 1's GPU budget was spent: run it under a hard timeout, separately from the regular suite
-FWAMD_TEST_UNVALIDATED=1 timeout 240 python -m pytest tests/test_gpu_vad.py tests/test_gpu_full_size.py -q -s 2>&1 \
-    | tail -15 > "$OUT/unvalidated_tests.log"
-cat "$OUT/unvalidated_tests.log"
-# int8 fragment-major decoder GEMM (opt-in at pack time): parity first, then speed against the LDS form
-FWAMD_DEC_GEMM_I8=frag timeout 200 python -m pytest tests/test_gpu_int8.py -q 2>&1 | tail -3 > "$OUT/int8_frag_tests.log"
-cat "$OUT/int8_frag_tests.log"
 for s in "A=0" "FWAMD_DEC_GEMM_I8=frag"; do
   timeout 150 env $s python profiles/sweep.py --compute-type int8_float16 --workers 1,8 --tag "int8 $s" \
       >> "$OUT/sweep_int8.jsonl" 2>> "$OUT/sweep.err"
