@@ -11,11 +11,21 @@ metric = audio seconds per wall second (whole job, all ranks).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; rank 0 packs the weight blob and broadcasts it over RCCL/xGMI,
-every rank processes its own batches (weak scaling, no data-path collective), per-step
-results are gathered to rank 0.
+`--workers` host threads (CTranslate2's inter_threads / faster-whisper's num_workers) each submit batches of 16;
+the workers of a GPU form a decode group: their encoders run side by side, their generate() calls are merged into
+shared decode runs (include/fwamd.h).  N > 1: one process per GPU; rank 0 packs the weight blob and broadcasts it
+over RCCL/xGMI, every rank processes its own batches (weak scaling, no data-path collective), per-step results
+are gathered to rank 0.
+
+Besides the metric the line carries (rank 0): `roofline` (dominant kernel family, HIP events on the engine's
+streams during a profiled round of the same workload), `cpu_baseline` (oracle port on the host cores, N = 1),
+and secondary measurements of the other SURVEY.md section 8 configurations: `pipeline` (section 8d wall-time
+definition: ndarray in host memory -> last Segment of a 1 h recording), `cap_case` (224 new tokens per chunk),
+`single_utterance` (C2: one 30 s chunk), and at N > 1 `sharded_recording` (C4: the 1 h recording sharded over
+the ranks — strong scaling).
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -39,45 +49,101 @@ def synth_chunks(n, seed):
     return [(0.1 * rng.standard_normal(480000) + tone).astype(np.float32) for _ in range(n)]
 
 
-def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0):
-    """Secondary, end-to-end number (SURVEY.md section 8d wall-time definition): BatchedInferencePipeline.transcribe
-    on one synthetic recording of n_chunks x 30 s that starts as an ndarray in HOST memory, timed until the last
-    Segment is yielded — includes the host->device copy of the PCM, prompt / suppress-set construction, timestamp
-    splitting and text rendering.  Decode length is fixed by suppressing <|endoftext|> up to max_new_tokens.
+def host_model(backend, cfg):
+    """the host-side WhisperModel shell around an already loaded backend (no tokenizer file exists offline)"""
+    import logging
+    from faster_whisper_amd.transcribe import FeatureExtractor, WhisperModel
+    wm = WhisperModel.__new__(WhisperModel)
+    wm.logger = logging.getLogger("bench")
+    wm.model = backend
+    wm.hf_tokenizer = None
+    wm.feature_extractor = FeatureExtractor(feature_size=cfg.n_mels, backend=backend)
+    wm.input_stride, wm.time_precision, wm.max_length = 2, 0.02, 448
+    wm.num_samples_per_token = wm.feature_extractor.hop_length * wm.input_stride
+    wm.frames_per_second, wm.tokens_per_second = 100, 50
+    return wm
+
+
+def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0, shard=False, sync=None,
+                 word_timestamps=False):
+    """End-to-end number (SURVEY.md section 8d wall-time definition): BatchedInferencePipeline.transcribe on one
+    synthetic recording of n_chunks x 30 s that starts as an ndarray in HOST memory, timed until the last Segment is
+    yielded — includes the host->device copy of the PCM, prompt / suppress-set construction, timestamp splitting and
+    text rendering.  Decode length is fixed by suppressing <|endoftext|> up to max_new_tokens.
+    shard=True: every rank of the torch.distributed job calls this; the chunk list is block-partitioned over the
+    ranks and rank 0 yields all segments (strong scaling); `sync` = barrier + device sync used to bracket the timing.
     -> dict for the bench line (never raises: a failure is reported as {"error": ...})."""
     try:
-        import logging
-        from faster_whisper_amd.transcribe import BatchedInferencePipeline, FeatureExtractor, WhisperModel
-        wm = WhisperModel.__new__(WhisperModel)        # host-side shell around the already loaded backend
-        wm.logger = logging.getLogger("bench")
-        wm.model = backend
-        wm.hf_tokenizer = None
-        wm.feature_extractor = FeatureExtractor(feature_size=cfg.n_mels, backend=backend)
-        wm.input_stride, wm.time_precision, wm.max_length = 2, 0.02, 448
-        wm.num_samples_per_token = wm.feature_extractor.hop_length * wm.input_stride
-        wm.frames_per_second, wm.tokens_per_second = 100, 50
+        from faster_whisper_amd.transcribe import BatchedInferencePipeline
+        wm = host_model(backend, cfg)
         chunks = synth_chunks(min(n_chunks, 8), seed=2000 + seed)
         audio = np.concatenate([chunks[i % len(chunks)] for i in range(n_chunks)])
         clips = [{"start": 30.0 * i, "end": 30.0 * (i + 1)} for i in range(n_chunks)]
         kw = dict(language="en", beam_size=beam, batch_size=batch, clip_timestamps=clips, max_new_tokens=new_tokens,
-                  suppress_tokens=[cfg.eot], without_timestamps=True)
+                  suppress_tokens=[cfg.eot], without_timestamps=True, word_timestamps=word_timestamps)
+        if shard:
+            kw["shard"] = True
         pipe = BatchedInferencePipeline(wm)
-        list(pipe.transcribe(audio[:480000 * min(n_chunks, batch)], **dict(kw, clip_timestamps=clips[:min(n_chunks, batch)]))[0])
+        n_warm = min(n_chunks, batch * max(1, int(getattr(backend, "inter_threads", 1))))
+        list(pipe.transcribe(audio[:480000 * n_warm], **dict(kw, clip_timestamps=clips[:n_warm]))[0])
+        if sync:
+            sync()
         t0 = time.perf_counter()
         segments, _ = pipe.transcribe(audio, **kw)
-        n_seg = n_tok = 0
+        n_seg = n_tok = n_words = 0
         for s in segments:
             n_seg += 1
             n_tok += len(s.tokens)
+            n_words += len(s.words or ())
+        if sync:
+            sync()
         dt = time.perf_counter() - t0
-        return {"value": round(30.0 * n_chunks / dt, 2), "unit": "audio-seconds per wall-second", "audio_s": 30.0 * n_chunks,
-                "wall_s": round(dt, 3), "segments": n_seg, "tokens": n_tok,
-                "what": "BatchedInferencePipeline.transcribe, ndarray in host memory -> last Segment"}
-    except Exception as e:   # the secondary number must never take the bench line down
+        out = {"value": round(30.0 * n_chunks / dt, 2), "unit": "audio-seconds per wall-second",
+               "audio_s": 30.0 * n_chunks, "wall_s": round(dt, 3), "segments": n_seg, "tokens": n_tok,
+               "what": "BatchedInferencePipeline.transcribe, ndarray in host memory -> last Segment"}
+        if word_timestamps:
+            out["words"] = n_words
+        return out
+    except Exception as e:   # a secondary number must never take the bench line down
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def main():
+def build_backend(args, cfg, rank, world, local_rank):
+    """-> (backend, weights or None).  N > 1: rank 0 packs, RCCL broadcast, every rank builds from its HBM copy."""
+    from faster_whisper_amd import Whisper, pack_blob, synthetic_weights
+    from faster_whisper_amd.sharding import broadcast_blob
+    ct = 1 if args.compute_type == "int8_float16" else 0
+    common = dict(device="cuda", device_index=local_rank, max_batch_size=args.batch, max_beam_size=args.beam,
+                  inter_threads=args.workers, compute_type=args.compute_type)
+    weights = None
+    if world > 1:
+        blob = None
+        if rank == 0:
+            weights = synthetic_weights(cfg, seed=1234)
+            blob = pack_blob(cfg, weights, ct)
+        dev_blob = broadcast_blob(blob, rank, local_rank)           # RCCL broadcast over xGMI
+        model = Whisper(f"synthetic:{args.model}", blob_dev=(dev_blob.data_ptr(), dev_blob.numel()), **common)
+        model._blob_keepalive = dev_blob
+    elif os.environ.get("FWAMD_BLOB_CACHE"):
+        # profiling convenience: repeated invocations (rocprofv3 passes) reuse one packed weight blob
+        import torch
+        cache = os.environ["FWAMD_BLOB_CACHE"] + f".{args.model}.{args.compute_type}.npy"
+        if os.path.exists(cache):
+            blob = np.load(cache, mmap_mode="r")
+        else:
+            weights = synthetic_weights(cfg, seed=1234)
+            blob = pack_blob(cfg, weights, ct)
+            np.save(cache, blob)
+        dev_blob = torch.from_numpy(np.array(blob, copy=True)).cuda()
+        model = Whisper(f"synthetic:{args.model}", blob_dev=(dev_blob.data_ptr(), dev_blob.numel()), **common)
+        model._blob_keepalive = dev_blob
+    else:
+        weights = synthetic_weights(cfg, seed=1234)
+        model = Whisper(f"synthetic:{args.model}", files={"config": cfg, "weights": weights}, **common)
+    return model, weights
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
@@ -87,86 +153,71 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=100)
     ap.add_argument("--workers", type=int, default=8,
-                    help="batches kept in flight per GPU (worker replicas sharing the weights)")
+                    help="host threads submitting batches per GPU (worker replicas: own encoder stream, shared "
+                         "weights, shared decode group)")
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
                     help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
+    ap.add_argument("--word-timestamps", action="store_true",
+                    help="the pipeline measurement runs with word_timestamps=True (config C5: align pass timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="also report the secondary end-to-end number (BatchedInferencePipeline on a 1 h recording that "
-                         "starts in host memory).  Opt-in: added after round 1's GPU budget was spent, not yet run on "
-                         "hardware, and the bench line must not depend on it")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (pipeline, cap_case, single_utterance, sharded_recording)")
     ap.add_argument("--pipeline-chunks", type=int, default=120, help="30 s chunks of the end-to-end recording (1 h)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main(argv=None, backend_factory=None, dist_backend=None):
+    """backend_factory / dist_backend: test seams (tests/test_bench_dist_gloo.py runs the N > 1 control flow on CPU
+    with a scripted backend over gloo); the benchmark itself never passes them."""
+    args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    on_gpu = dist_backend in (None, "nccl")
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        kw = {}
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        # a rank that fails before a collective must not leave the others waiting for ever
+        dist.init_process_group(dist_backend or "nccl", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=300), **kw)
 
-    from faster_whisper_amd import Whisper, get_config, pack_blob, synthetic_weights
-    from faster_whisper_amd.sharding import broadcast_blob, gather_results
+    from faster_whisper_amd import get_config
+    from faster_whisper_amd.sharding import gather_results
 
     cfg = get_config(args.model)
     t0 = time.time()
-    weights = None
-    if world > 1:
-        blob = None
-        if rank == 0:
-            weights = synthetic_weights(cfg, seed=1234)
-            blob = pack_blob(cfg, weights, 1 if args.compute_type == "int8_float16" else 0)
-        dev_blob = broadcast_blob(blob, rank, local_rank)           # RCCL broadcast over xGMI
-        model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
-                        max_batch_size=args.batch, max_beam_size=args.beam, inter_threads=args.workers,
-                        compute_type=args.compute_type, blob_dev=(dev_blob.data_ptr(), dev_blob.numel()))
-    elif os.environ.get("FWAMD_BLOB_CACHE"):
-        # profiling convenience: repeated invocations (rocprofv3 passes) reuse one packed weight blob
-        import torch
-        cache = os.environ["FWAMD_BLOB_CACHE"]
-        if os.path.exists(cache):
-            blob = np.load(cache, mmap_mode="r")
-        else:
-            weights = synthetic_weights(cfg, seed=1234)
-            blob = pack_blob(cfg, weights, 1 if args.compute_type == "int8_float16" else 0)
-            np.save(cache, blob)
-        dev_blob = torch.from_numpy(np.array(blob, copy=True)).cuda()
-        model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
-                        max_batch_size=args.batch, max_beam_size=args.beam, inter_threads=args.workers,
-                        compute_type=args.compute_type, blob_dev=(dev_blob.data_ptr(), dev_blob.numel()))
-    else:
-        weights = synthetic_weights(cfg, seed=1234)
-        model = Whisper(f"synthetic:{args.model}", device="cuda", device_index=local_rank,
-                        files={"config": cfg, "weights": weights}, max_batch_size=args.batch,
-                        max_beam_size=args.beam, inter_threads=args.workers, compute_type=args.compute_type)
+    model, weights = (backend_factory or build_backend)(args, cfg, rank, world, local_rank)
     load_s = time.time() - t0
 
     chunks = synth_chunks(args.batch, seed=1000 + rank)
     staged = model.stage_pcm(chunks)
     prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
     L = args.new_tokens
-    gen_kw = dict(beam_size=args.beam, patience=1.0, length_penalty=1.0, max_length=len(prompt) + L,
-                  return_scores=True, return_no_speech_prob=True, suppress_blank=True,
-                  suppress_tokens=[cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe],
-                  min_new_tokens=L)
+    sup = [cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe]
 
-    def step():
+    def gen_kw(n):
+        return dict(beam_size=args.beam, patience=1.0, length_penalty=1.0, max_length=len(prompt) + n,
+                    return_scores=True, return_no_speech_prob=True, suppress_blank=True, suppress_tokens=sup,
+                    min_new_tokens=n)
+
+    def step(n=L):
         enc = model.encode_pcm_staged(staged)
-        return model.generate(enc, [prompt] * args.batch, **gen_kw)
+        return model.generate(enc, [prompt] * args.batch, **gen_kw(n))
 
     def barrier():
         if world > 1:
             dist.barrier()
-        for r in model._replicas:
-            model._lib.fw_synchronize(r.handle)
+        model.synchronize()
 
-    # W host threads, one worker replica (stream + workspaces, shared weights) each: the batches of
-    # a long recording are independent, so several are kept in flight on the GPU at once.
+    # W host threads, one worker replica (encoder stream + workspaces, shared weights) each: the batches of a long
+    # recording are independent, so several are kept in flight on the GPU at once.
     from concurrent.futures import ThreadPoolExecutor
     import threading
     W = max(1, args.workers)
@@ -179,53 +230,81 @@ def main():
             r = step()
         return r
 
-    def run_steps(n):
-        futs = [pool.submit(step) for _ in range(n)]
+    def run_steps(n, n_tok=L, gather=True):
+        futs = [pool.submit(step, n_tok) for _ in range(n)]
         outs = []
         for f in futs:                   # results come back in submission order = chunk order
             r = f.result()
-            if world > 1:
-                gather_results(r, L, rank, world, local_rank)
+            if world > 1 and gather:
+                gather_results(r, n_tok, rank, world, local_rank)
             outs.append(r)
         return outs
 
+    def timed(n, n_tok=L):
+        barrier()
+        t1 = time.perf_counter()
+        res = run_steps(n, n_tok)[-1]
+        barrier()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            import torch
+            tt = torch.tensor([dt], device=f"cuda:{local_rank}" if on_gpu else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert all(len(r.sequences_ids[0]) == n_tok for r in res), "decode length is not the requested fixed length"
+        return dt
+
     if args.warmup > 0:
-        res = list(pool.map(warm, range(W)))[-1]
-    barrier()
-    t1 = time.perf_counter()
-    res = run_steps(args.steps)[-1]
-    barrier()
-    elapsed = time.perf_counter() - t1
-    if world > 1:
-        import torch
-        tt = torch.tensor([elapsed], device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert all(len(r.sequences_ids[0]) == L for r in res), "decode length is not the requested fixed length"
+        list(pool.map(warm, range(W)))
+    stats0 = model.decode_stats()
+    elapsed = timed(args.steps)
+    stats1 = model.decode_stats()
 
     audio_s = 30.0 * args.batch * args.steps * world
     value = audio_s / elapsed
-
+    runs = max(1, stats1["runs"] - stats0["runs"])
     out = {
         "metric": "audio-sec/sec (RTF) large-v3 fp16 beam=5 batch=16", "value": round(value, 2),
         "unit": "audio-seconds per wall-second", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / max(1, args.steps), 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.compute_type == "float16" else "i8/f16", "data": "synthetic",
-        "config": {"workload": f"{args.model} {args.compute_type} BatchedInferencePipeline hot path: {args.batch} x 30 s chunks/step, "
-                               f"beam_size={args.beam}, {L} new tokens/chunk (fixed), PCM resident in HBM",
-                   "global_batch": args.batch * world, "new_tokens": L, "batches_in_flight_per_gpu": W, "model_load_s": round(load_s, 1)},
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.compute_type == "float16" else "i8/f16",
+        "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.compute_type} BatchedInferencePipeline hot path: {args.batch} x 30 s "
+                               f"chunks/step, beam_size={args.beam}, {L} new tokens/chunk (fixed), PCM resident in HBM",
+                   "global_batch": args.batch * world, "new_tokens": L, "workers_per_gpu": W,
+                   "decode_group": {"capacity_chunks": stats1["decode_batch"], "decode_runs": runs,
+                                    "chunks_per_run": round((stats1["chunks"] - stats0["chunks"]) / runs, 1),
+                                    "largest_run_chunks": stats1["max_run_chunks"]},
+                   "model_load_s": round(load_s, 1)},
     }
 
+    secondary = not args.no_secondary
+    # ---- secondary, all ranks take part: the cap case and (N > 1) the sharded recording ----
+    if secondary:
+        n2 = max(W, min(args.steps, 2 * W))
+        run_steps(W, 224, gather=False)        # graph capture etc. for the other decode length
+        dt2 = timed(n2, 224)
+        out["cap_case"] = {"new_tokens": 224, "value": round(30.0 * args.batch * n2 * world / dt2, 2),
+                           "unit": "audio-seconds per wall-second", "steps": n2}
+        if world > 1:
+            out["sharded_recording"] = dict(
+                pipeline_rtf(model, cfg, args.pipeline_chunks, args.batch, args.beam, L, shard=True, sync=barrier),
+                scaling="strong", n_gpus=world)
+
     if rank == 0:
-        # ---- roofline of the dominant kernel family: profiled pass (HIP events on the engine stream) ----
+        # ---- roofline of the dominant kernel family: one profiled round of the same workload (HIP events on the
+        #      engine's streams; the decode step runs eagerly instead of as a graph replay while profiling) ----
         if not args.no_profile_pass:
-            ridx = model._replicas.index(model._replica_for(None))   # the main thread's worker
-            model.profile(True, replica=ridx)
-            step()
-            rep = model.profile_report(replica=ridx)
-            model.profile(False, replica=ridx)
+            model.profile(True, replica=None)
+            run_steps(W, gather=False)
+            model.synchronize()
+            rep = model.profile_report(replica=None)
+            model.profile(False, replica=None)
+            for v in rep.values():             # per batch-step
+                for f in ("ms", "bytes", "flops"):
+                    v[f] /= W
             tot = sum(v["ms"] for v in rep.values())
-            # the six per-layer decoder linears are ONE kernel (dec_gemm_lds_kernel); their four timing
+            # the six per-layer decoder linears are ONE kernel (dec_gemm_frag_kernel); their four timing
             # families are merged before the dominant kernel is picked
             merged = {k: dict(v) for k, v in rep.items() if not k.startswith("dec_gemm_")}
             parts = [v for k, v in rep.items() if k.startswith("dec_gemm_")]
@@ -243,7 +322,9 @@ def main():
             roof["kernel"] = name
             roof["traffic"] = pmc_traffic(name)
             roof["kernel_ms_per_step"] = round(dom["ms"], 3)
-            roof["launch_groups_per_step"] = dom["launches"]
+            roof["launch_groups_in_round"] = dom["launches"]
+            roof["timing"] = (f"HIP events around every launch on the engine's streams, one round of {W} batches with "
+                              "all workers active (as in the timed region), divided by the batches")
             out["roofline"] = roof
             out["families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in rep.items()}
             out["families_sum_ms"] = round(tot, 3)
@@ -256,30 +337,55 @@ def main():
                 elif v["bytes"] > 0:
                     fam[k] = {"GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
             out["families_rate"] = fam
+        if secondary and world == 1:
+            out["pipeline"] = pipeline_rtf(model, cfg, args.pipeline_chunks, args.batch, args.beam, L,
+                                           word_timestamps=args.word_timestamps)
+            out["single_utterance"] = single_utterance(model, cfg, chunks[0], prompt, gen_kw(L), L)
         # ---- CPU baseline: the oracle (torch fp32 port) on a bounded sample of the same workload ----
-        if args.pipeline and world == 1:
-            out["pipeline"] = pipeline_rtf(model, cfg, args.pipeline_chunks, args.batch, args.beam, L)
         # (reported at N = 1 only: at N > 1 the other ranks would idle at the final barrier while it runs)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks[0], prompt, args.beam, L, gen_kw)
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks[0], prompt, args.beam, L, gen_kw(L))
         print(json.dumps(out), flush=True)
     model.free_staged(staged)
+    pool.shutdown()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
 
 
-_PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "gemm_f16_kernel",
-               "enc_attn": "attn_enc_kernel", "dec_gemm": "dec_gemm_frag_kernel"}
+def single_utterance(model, cfg, chunk, prompt, kw, L, reps=3):
+    """config C2: ONE 30 s utterance, beam 5 (latency-bound: 5 decoder rows) — PCM from host memory, log-mel,
+    encoder, decode, results on the host"""
+    try:
+        best = None
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            enc = model.encode_pcm([chunk])
+            r = model.generate(enc, [prompt], **kw)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)     # first iteration warms the graph for this shape
+        assert len(r[0].sequences_ids[0]) == L
+        return {"value": round(30.0 / best, 2), "unit": "audio-seconds per wall-second", "latency_ms": round(1e3 * best, 1),
+                "what": f"one 30 s chunk, beam 5, {L} new tokens, host PCM -> ids on the host (best of {reps})"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+_PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "gemm_f16", "enc_attn": "attn_enc_kernel",
+               "dec_gemm": "dec_gemm_frag_kernel", "dec_self_attn": "dec_self_attn_kernel",
+               "dec_logits": "dec_gemm_wave_kernel"}
 
 
 def pmc_traffic(family):
-    """HBM read bytes per launch of the family's kernel from the committed rocprofv3 --pmc FETCH_SIZE pass
-    (profiles/r01_pmc_fetch.json, x2 gfx950 correction already applied by profiles/parse_pmc.py); null if
-    that kernel was not measured."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")
-    if not os.path.exists(path) or family not in _PMC_KERNEL:
+    """HBM read bytes per launch of the family's kernel from the newest committed rocprofv3 --pmc FETCH_SIZE pass
+    (profiles/rNN_pmc_fetch*.json, x2 gfx950 correction already applied by profiles/parse_pmc.py); null if that
+    kernel was not measured."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch*.json")))
+    if not files or family not in _PMC_KERNEL:
         return None
+    path = files[-1]
     with open(path) as f:
         j = json.load(f)
     tot = n = 0.0
@@ -291,7 +397,8 @@ def pmc_traffic(family):
             n += d
     if n == 0:
         return None
-    return {"hbm_read_bytes_per_launch": round(tot / n), "source": "profiles/r01_pmc_fetch.json"}
+    return {"hbm_read_bytes_per_launch": round(tot / n), "source": os.path.relpath(path, ROOT),
+            "note": "that pass profiles one batch at a time (16 chunks per decode run)"}
 
 
 def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
@@ -304,7 +411,8 @@ def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
     if weights is None:
         from faster_whisper_amd import synthetic_weights
         weights = synthetic_weights(cfg, seed=1234)
-    cores = min(os.cpu_count() or 1, 32)   # more threads only add synchronisation cost at these sizes
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 32)   # more threads only add synchronisation cost at these sizes
     torch.set_num_threads(cores)
     oracle = OracleWhisper(cfg, weights, emulate_fp16=False)
 
@@ -332,11 +440,13 @@ def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
     per_step = max(1e-6, (t4 - t1) / 3)
     fixed = max(0.0, t1 - per_step)              # cross-K/V projection + prompt forward
     total = t_mel + t_enc + fixed + per_step * L
-    return {"value": round(30.0 / total, 4), "unit": "audio-seconds per wall-second", "cores": cores, "kind": "port",
+    return {"value": round(30.0 / total, 4), "unit": "audio-seconds per wall-second", "cores": cores,
+            "host_cores": host_cores, "kind": "port",
             "sample": f"1 chunk (30 s): numpy log-mel {t_mel:.2f}s; encoder convs {t0l:.2f}s + {n_meas_layers} of "
                       f"{cfg.n_enc_layers} blocks measured ({per_layer:.2f}s/block) -> {t_enc:.1f}s; cross-KV+prompt "
                       f"{fixed:.2f}s; 3 beam-{beam} steps measured ({per_step * 1e3:.0f} ms/step) -> {L} steps; "
-                      f"torch fp32 restatement (oracle/) on {cores} threads, not CTranslate2"}
+                      f"torch fp32 restatement (oracle/) on {cores} of the box's {host_cores} hardware threads, not "
+                      "CTranslate2 (absent offline: BASELINE.md section 3)"}
 
 
 if __name__ == "__main__":

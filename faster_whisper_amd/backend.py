@@ -192,6 +192,14 @@ def save_model_dir(path: str, cfg: WhisperConfig, weights: Dict[str, np.ndarray]
     save_file({k: np.ascontiguousarray(v) for k, v in weights.items()}, os.path.join(path, "weights.safetensors"))
 
 
+def call_seed(n: int) -> int:
+    """seed of the n-th sampling call of a model (splitmix64 of the call counter)"""
+    z = (n * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
 class Whisper:
     """Drop-in for ctranslate2.models.Whisper on MI355X.
 
@@ -232,16 +240,25 @@ class Whisper:
         # one replica per (device, worker): the `inter_threads` workers of a device share ONE copy of the
         # weights in HBM and own a stream + workspaces each (CTranslate2 replica pool semantics,
         # transcribe.py:645-657), so concurrent transcribe() threads overlap on the GPU
+        # The workers of a device form a DECODE GROUP (include/fwamd.h): they share one decode workspace sized
+        # for all of their batches, and generate() calls that arrive concurrently are merged into one decode run
+        # whose rows share every weight byte streamed per step.  decode_group=False keeps a decoder per worker.
         self._replicas = []
+        decode_group = bool(kwargs.pop("decode_group", True))
         for i in idx:
             primary = _Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev)
             self._replicas.append(primary)
             if inter_threads > 1:
                 p, n = C.c_void_p(), C.c_int64()
                 _lib.check(self._lib.fw_model_blob(primary.handle, C.byref(p), C.byref(n)))
+                if decode_group:
+                    _lib.check(self._lib.fw_model_set_decode_batch(primary.handle, inter_threads * max_batch_size))
                 for _ in range(inter_threads - 1):
-                    self._replicas.append(_Replica(cfg, None, ct, i, max_batch_size, max_beam_size,
-                                                   (p.value, n.value)))
+                    r = _Replica(cfg, None, ct, i, max_batch_size, max_beam_size, (p.value, n.value))
+                    if decode_group:
+                        _lib.check(self._lib.fw_model_join_decoder(r.handle, primary.handle))
+                    self._replicas.append(r)
+        self._seed_counter = itertools.count(1)
         self._rr = itertools.count()
         self._tls = threading.local()
         self.inter_threads = len(self._replicas)   # batches the host drivers may keep in flight
@@ -274,6 +291,19 @@ class Whisper:
     @property
     def config(self) -> WhisperConfig:
         return self._cfg
+
+    def synchronize(self):
+        """block until everything queued on the encoder and decode streams of every worker has finished"""
+        for r in self._replicas:
+            _lib.check(self._lib.fw_synchronize(r.handle))
+
+    def decode_stats(self) -> dict:
+        """counters of the decode group of device 0: how many generate() calls shared how many decode runs"""
+        runs, reqs, chunks, mx = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        _lib.check(self._lib.fw_model_decode_stats(self._replicas[0].handle, C.byref(runs), C.byref(reqs),
+                                                   C.byref(chunks), C.byref(mx)))
+        return {"runs": runs.value, "requests": reqs.value, "chunks": chunks.value, "max_run_chunks": mx.value,
+                "decode_batch": int(self._lib.fw_model_decode_batch(self._replicas[0].handle))}
 
     def _replica_for(self, features: Optional[StorageView]) -> _Replica:
         if features is not None and features._owner is not None:
@@ -376,7 +406,7 @@ class Whisper:
                  max_initial_timestamp_index: int = 50, suppress_blank: bool = True,
                  suppress_tokens: Optional[Sequence[int]] = (-1,), sampling_topk: int = 1,
                  sampling_temperature: float = 1, min_new_tokens: int = 0,
-                 seed: int = 0) -> List[WhisperGenerationResult]:
+                 seed: Optional[int] = None) -> List[WhisperGenerationResult]:
         if asynchronous or return_logits_vocab:
             raise ValueError("asynchronous / return_logits_vocab are not supported (unused by faster-whisper)")
         enc = self._as_encoded(features if isinstance(features, StorageView) else StorageView.from_array(features))
@@ -396,6 +426,10 @@ class Whisper:
         o.suppress_tokens = _lib.as_i32p(sup) if sup.size else None
         o.n_suppress_tokens = int(sup.size)
         o.sampling_topk, o.sampling_temperature = int(sampling_topk), float(sampling_temperature)
+        if seed is None:
+            # CTranslate2 draws from a global generator that advances from call to call; here every sampling call
+            # gets a seed of its own from a per-model counter (explicit seeds reproduce a call exactly)
+            seed = call_seed(next(self._seed_counter))
         o.seed, o.min_new_tokens = int(seed), int(min_new_tokens)
         nh = max(1, int(num_hypotheses))
         ml = max(1, int(max_length))
@@ -456,22 +490,36 @@ class Whisper:
         return out
 
     # ---- measurement --------------------------------------------------------------------
-    def profile(self, enable: bool = True, replica: int = 0):
-        self._lib.fw_prof_enable(self._replicas[replica].handle, int(enable))
-        self._lib.fw_prof_reset(self._replicas[replica].handle)
+    def _primary_of(self, replica: int) -> int:
+        """index of the replica that owns the decode workspace of `replica`'s device (the first one of the device)"""
+        dev = self._replicas[replica].device_index
+        return next(i for i, r in enumerate(self._replicas) if r.device_index == dev)
 
-    def profile_report(self, replica: int = 0) -> Dict[str, dict]:
+    def profile(self, enable: bool = True, replica: Optional[int] = 0):
+        """per-kernel-family HIP-event timing.  replica=None: every worker.  Decode-side families are recorded by
+        the replica that owns the device's decode workspace, so that one is switched along."""
+        idx = range(len(self._replicas)) if replica is None else sorted({replica, self._primary_of(replica)})
+        for i in idx:
+            self._lib.fw_prof_enable(self._replicas[i].handle, int(enable))
+            self._lib.fw_prof_reset(self._replicas[i].handle)
+
+    def profile_report(self, replica: Optional[int] = 0) -> Dict[str, dict]:
         out = {}
-        h = self._replicas[replica].handle
-        for i in range(self._lib.fw_prof_count()):
-            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-            _lib.check(self._lib.fw_prof_get(h, i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
-            out[self._lib.fw_prof_name(i).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value,
-                                                           bytes=by.value)
+        idx = range(len(self._replicas)) if replica is None else sorted({replica, self._primary_of(replica)})
+        for r in idx:
+            h = self._replicas[r].handle
+            for i in range(self._lib.fw_prof_count()):
+                ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+                _lib.check(self._lib.fw_prof_get(h, i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+                acc = out.setdefault(self._lib.fw_prof_name(i).decode(), dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                acc["ms"] += ms.value
+                acc["launches"] += n.value
+                acc["flops"] += fl.value
+                acc["bytes"] += by.value
         return out
 
     def unload_model(self):
-        for r in self._replicas:
+        for r in reversed(self._replicas):     # workers before the replica whose decoder / weights they share
             r.close()
 
     def __del__(self):

@@ -20,20 +20,12 @@ struct GenDev {
   int sample;              // 1: draw the next token from softmax(logp / T) instead of arg-max / beam
   float inv_temp;
   unsigned seed_lo, seed_hi;
+  int kv_div;              // decode chunks per encoder chunk (sampling: num_hypotheses), 1 otherwise
 };
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d,
                   const int* d_step, int pos_fixed, int P);
-int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
-                    const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
-                    bool out_f32);
-int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
-                        const float* cf, const half_t* res, int ldr, half_t* out, int ldo, int R, int N, int K,
-                        int act);
-int launch_dec_gemm_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq, const float* w_scale,
-                       const half_t* bias, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
-                       bool out_f32);
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag);
@@ -46,6 +38,9 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
 int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq,
                             const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
                             int R, int N, int K, int act);
+// vocabulary projection -> float32 logits; operands fragment-major (Wf: ceil(N/16) column tiles, zero-padded)
+int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_scale, const void* Wf,
+                      const float* w_scale, const float* s1, const float* cf, float* out, int ldo, int R, int N, int K);
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
 void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
                            const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok);

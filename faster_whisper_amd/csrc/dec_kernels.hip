@@ -45,361 +45,6 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
 }
 
 // ------------------------------------------------------------------------------------
-// K13/K15/K16: skinny GEMM  out[r][n] = epi( sum_k x[r][k] W[n][k] ),  r < R <= 16*MT
-//
-// Weight-streaming kernel (HBM-bound: every weight byte is read exactly once per step).
-// One workgroup owns 16*NTW output columns; its 4 waves split K and reduce through LDS in
-// a fixed order (deterministic).  v_mfma_f32_16x16x32_f16 with A = W rows (n), B = x rows,
-// so a lane ends with 4 consecutive n of one row.  The K loop is software-pipelined by
-// hand: two register sets of CH k-steps each, the loads of the next chunk (W from HBM, x
-// from L2) are all issued before the MFMAs of the current one, so >= CH*(NTW+MT) 16-byte
-// loads per lane are always in flight (a step is latency-bound otherwise).
-//
-// LNF: the LayerNorm that precedes this linear is folded in (decoder rows are few, a
-// LayerNorm launch would be pure launch overhead).  With wf = W.g (packed at load time):
-//      y = rstd_r * ( wf x_r - mu_r * s1 ) + cf
-// mu/rstd come from sum / sum-of-squares of the raw x fragments the lanes hold anyway
-// (v_dot2c_f32_f16), reduced over the 4 k-groups of a row and the 4 waves.
-// ------------------------------------------------------------------------------------
-template <int MT, int NTW, int CH>
-struct DgFrag {
-  half8_t w[CH][NTW];
-  half8_t x[CH][MT];
-};
-
-template <int MT, int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool OUT_F32>
-__global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(const half_t* __restrict__ x, int ldx,
-                                                       const half_t* __restrict__ W,
-                                                       const half_t* __restrict__ bias,
-                                                       const float* __restrict__ s1, const float* __restrict__ cf,
-                                                       const half_t* __restrict__ res, int ldr, void* __restrict__ outv,
-                                                       int ldo, int R, int N, int K, int act) {
-  extern __shared__ __attribute__((aligned(16))) float dg_smem[];
-  float* red = dg_smem;                                  // [WAVES][MT*NTW][64][4]
-  float* stat = dg_smem + WAVES * MT * NTW * 256;        // [WAVES][MT][16][2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * (16 * NTW);
-  const int kq = K / WAVES;  // per-wave K range
-  const int kbase = wave * kq + g * 8;
-  const int steps = kq >> 5;
-  const half_t* wp[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    int wrow = n0 + t * 16 + i; if (wrow > N - 1) wrow = N - 1;
-    wp[t] = W + (size_t)wrow * K + kbase;
-  }
-  const half_t* xp[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int xr = mt * 16 + i; if (xr > R - 1) xr = R - 1;
-    xp[mt] = x + (size_t)xr * ldx + kbase;
-  }
-  floatx4 acc[MT][NTW];
-  float rs[MT], rq[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    rs[mt] = 0.f; rq[mt] = 0.f;
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[mt][t] = floatx4{0, 0, 0, 0};
-  }
-  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto load = [&](DgFrag<MT, NTW, CH>& f, int ks0) {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int ks = ks0 + j;
-      if (ks < steps) {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) f.w[j][t] = *reinterpret_cast<const half8_t*>(wp[t] + ks * 32);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) f.x[j][mt] = *reinterpret_cast<const half8_t*>(xp[mt] + ks * 32);
-      } else {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) f.w[j][t] = zero8;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) f.x[j][mt] = zero8;
-      }
-    }
-  };
-  auto compute = [&](const DgFrag<MT, NTW, CH>& f) {
-#pragma unroll
-    for (int j = 0; j < CH; ++j)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[j][t], f.x[j][mt], acc[mt][t], 0, 0, 0);
-        if (LNF) {
-          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const half2_t h2 = {f.x[j][mt][2 * e], f.x[j][mt][2 * e + 1]};
-            rs[mt] = __builtin_amdgcn_fdot2(h2, one2, rs[mt], false);
-            rq[mt] = __builtin_amdgcn_fdot2(h2, h2, rq[mt], false);
-          }
-        }
-      }
-  };
-  if (ONESHOT) {
-    // the wave's whole K range fits one register set: every load of the launch is in flight at once
-    DgFrag<MT, NTW, CH> fa;
-    load(fa, 0);
-    compute(fa);
-  } else {
-    DgFrag<MT, NTW, CH> fa, fb;
-    load(fa, 0);
-    for (int ks0 = 0; ks0 < steps; ks0 += 2 * CH) {
-      load(fb, ks0 + CH);
-      compute(fa);
-      load(fa, ks0 + 2 * CH);
-      compute(fb);
-    }
-  }
-  // ---- cross-wave reduction (fixed order) ----
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[((wave * MT * NTW + mt * NTW + t) * 64 + lane) * 4 + e] = acc[mt][t][e];
-  if (LNF) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float a = rs[mt], b = rq[mt];
-      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      if (g == 0) {
-        stat[((wave * MT + mt) * 16 + i) * 2] = a;
-        stat[((wave * MT + mt) * 16 + i) * 2 + 1] = b;
-      }
-    }
-  }
-  __syncthreads();
-  for (int idx = wave; idx < MT * NTW; idx += WAVES) {
-    const int mt = idx / NTW, t = idx - mt * NTW;
-    const int row = mt * 16 + i;
-    if (row >= R) continue;
-    const int n = n0 + t * 16 + 4 * g;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int o = (idx * 64 + lane) * 4 + e;
-      const int ws = MT * NTW * 256;
-      float a = red[o];
-#pragma unroll
-      for (int w = 1; w < WAVES; ++w) a += red[w * ws + o];   // fixed order: deterministic
-      v[e] = a;
-    }
-    float mu = 0.f, rstd = 1.f;
-    if (LNF) {
-      float sa = 0.f, sb = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        sa += stat[((w * MT + mt) * 16 + i) * 2];
-        sb += stat[((w * MT + mt) * 16 + i) * 2 + 1];
-      }
-      mu = sa / (float)K;
-      const float var = fmaxf(sb / (float)K - mu * mu, 0.f);
-      rstd = rsqrtf(var + 1e-5f);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (n + e >= N) continue;
-      float tv = v[e];
-      if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-      else if (bias) tv += (float)bias[n + e];
-      if (act == 1) tv = gelu_erf(tv);
-      if (res) tv += (float)res[(size_t)row * ldr + n + e];
-      if (OUT_F32)
-        reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = tv;
-      else
-        reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)tv;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// Skinny GEMM, LDS-staged form (the per-layer decoder linears).
-//
-// rocprof showed the register-fragment form above spends its time in the texture-address unit:
-// an MFMA 16x16 fragment load puts 16 DIFFERENT rows on 16 consecutive lanes (16 cache lines per
-// quad, 64 B of each used), so the 80 activation rows re-read by every workgroup arrive at
-// ~20 B/clk/CU.  Here both operands go HBM/L2 -> LDS by direct DMA (global_load_lds, 16 B per lane,
-// full 640-byte row runs, no VGPR round trip) and the fragments are read from LDS, where the
-// scattered pattern is free (rows padded by one 16-byte slot => conflict-free ds_read_b128).
-//   * one workgroup = 16*NTW output columns x all K, K walked in slices of KQ = 8*KO through a
-//     2-slot LDS ring; slice q+1 is in flight while slice q is multiplied (counted vmcnt + raw
-//     s_barrier, never a full drain inside the loop);
-//   * the 4 waves own DIFFERENT activation row tiles (wave w: tiles w, w+4): no cross-wave
-//     reduction, the LayerNorm statistics of a row stay inside the wave that owns it.
-// ------------------------------------------------------------------------------------
-// I8 (int8_float16, K25): x and W are int8 with per-row de-quantisation scales (x_scale[r], w_scale[n]);
-// a 16-byte piece then holds 16 elements, v_mfma_i32_16x16x64_i8 accumulates in int32.
-template <int MT, int NTW, int KO, int DEPTH, bool LNF, bool OUT_F32, bool I8>
-__global__ __launch_bounds__(256) void dec_gemm_lds_kernel(const half_t* __restrict__ x, int ldx,
-                                                           const half_t* __restrict__ W,
-                                                           const half_t* __restrict__ bias,
-                                                           const float* __restrict__ s1, const float* __restrict__ cf,
-                                                           const half_t* __restrict__ res, int ldr,
-                                                           void* __restrict__ outv, int ldo, int R, int N, int K,
-                                                           int act, const float* __restrict__ x_scale,
-                                                           const float* __restrict__ w_scale) {
-  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
-  constexpr int ES = I8 ? 1 : 2, EPP = 16 / ES;              // element size, elements per 16-byte piece
-  constexpr int KQ = EPP * KO, STRIDE = KO + 1, NKS = KO / 4;  // MFMA k-steps per slice
-  constexpr int XROWS = MT * 16, XSLOTS = XROWS * STRIDE, XPAD = (XSLOTS + 255) / 256 * 256;
-  constexpr int WROWS = NTW * 16, WSLOTS = WROWS * STRIDE, WPAD = (WSLOTS + 255) / 256 * 256;
-  constexpr int NX = XPAD / 256, NW = WPAD / 256, NI = NX + NW;   // DMA instructions per wave per slice
-  constexpr int SLOT_BYTES = (XPAD + WPAD) * 16;
-  constexpr int MYT = (MT + 3) / 4;                               // row tiles per wave (max)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches below
-  const int i = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * (16 * NTW);
-  const int nq = K / KQ;
-  // blockIdx.y = activation row group (MT tiles each): short-N GEMMs are split over rows too so that
-  // all 256 CUs pull data (a CU sustains only ~50 GB/s of L2->LDS DMA)
-  const int row0 = blockIdx.y * (MT * 16);
-  R -= row0;
-  if (R <= 0) return;
-  const char* xb = reinterpret_cast<const char*>(x) + (size_t)row0 * ldx * ES;
-  const char* Wb = reinterpret_cast<const char*>(W);
-  if (I8) x_scale += row0;
-  if (res) res += (size_t)row0 * ldr;
-  if (OUT_F32) outv = reinterpret_cast<float*>(outv) + (size_t)row0 * ldo;
-  else outv = reinterpret_cast<half_t*>(outv) + (size_t)row0 * ldo;
-
-  auto issue = [&](int q, int slot) {
-    char* sbase = gl_smem + slot * SLOT_BYTES;
-    const int k0 = q * KQ;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const int base = (wave + 4 * j) * 64;
-      int s = base + lane;
-      if (s > XSLOTS - 1) s = XSLOTS - 1;
-      int row = s / STRIDE, kk = s - row * STRIDE;
-      if (row > R - 1) row = R - 1;
-      if (kk > KO - 1) kk = KO - 1;
-      const char* src = xb + ((size_t)row * ldx + k0 + kk * EPP) * ES;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + base * 16), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int base = (wave + 4 * j) * 64;
-      int s = base + lane;
-      if (s > WSLOTS - 1) s = WSLOTS - 1;
-      int row = s / STRIDE, kk = s - row * STRIDE;
-      if (kk > KO - 1) kk = KO - 1;
-      int wrow = n0 + row; if (wrow > N - 1) wrow = N - 1;
-      const char* src = Wb + ((size_t)wrow * K + k0 + kk * EPP) * ES;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + (XPAD + base) * 16), 16, 0,
-                                       0);
-    }
-  };
-
-  floatx4 acc[MYT][NTW];
-  intx4 acci[MYT][NTW];
-  float rs[MYT], rq[MYT];
-#pragma unroll
-  for (int a = 0; a < MYT; ++a) {
-    rs[a] = 0.f; rq[a] = 0.f;
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) { acc[a][t] = floatx4{0, 0, 0, 0}; acci[a][t] = intx4{0, 0, 0, 0}; }
-  }
-
-  // DEPTH-slot ring: slices q+1 .. q+DEPTH-2 stay in flight while slice q is multiplied; the slot
-  // freed by slice q-1 is refilled right after the barrier that proves everyone is done with it.
-#pragma unroll
-  for (int sidx = 0; sidx < DEPTH - 1; ++sidx)
-    if (sidx < nq) issue(sidx, sidx);
-  for (int q = 0; q < nq; ++q) {
-    int pending = nq - 1 - q;
-    if (pending > DEPTH - 2) pending = DEPTH - 2;
-    if (pending <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    else if (pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
-    __builtin_amdgcn_s_barrier();   // slice q has landed for every wave; slice q-1 is fully consumed
-    if (q + DEPTH - 1 < nq) issue(q + DEPTH - 1, (q + DEPTH - 1) % DEPTH);
-    const half8_t* xs = reinterpret_cast<const half8_t*>(gl_smem + (q % DEPTH) * SLOT_BYTES);
-    const half8_t* ws = xs + XPAD;
-    // all fragment reads of the slice are issued before the first MFMA needs them
-    half8_t wf[NKS][NTW];
-#pragma unroll
-    for (int j = 0; j < NKS; ++j)
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) wf[j][t] = ws[(t * 16 + i) * STRIDE + j * 4 + g];
-#pragma unroll
-    for (int a = 0; a < MYT; ++a) {
-      const int mt = wave + 4 * a;
-      if (mt < MT) {
-        half8_t xf[NKS];
-#pragma unroll
-        for (int j = 0; j < NKS; ++j) xf[j] = xs[(mt * 16 + i) * STRIDE + j * 4 + g];
-#pragma unroll
-        for (int j = 0; j < NKS; ++j) {
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            if (I8)
-              acci[a][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(intx4, wf[j][t]),
-                                                               __builtin_bit_cast(intx4, xf[j]), acci[a][t], 0, 0, 0);
-            else
-              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][t], xf[j], acc[a][t], 0, 0, 0);
-          }
-          if (LNF) {
-            const half2_t one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const half2_t h2 = {xf[j][2 * e], xf[j][2 * e + 1]};
-              rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
-              rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
-            }
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are complete
-  }
-  // ---- epilogue: each wave owns its rows outright ----
-#pragma unroll
-  for (int a = 0; a < MYT; ++a) {
-    const int mt = wave + 4 * a;
-    if (mt >= MT) continue;
-    const int row = mt * 16 + i;
-    float mu = 0.f, rstd = 1.f;
-    if (LNF) {
-      float sa = rs[a], sb = rq[a];
-      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-      mu = sa / (float)K;
-      const float var = fmaxf(sb / (float)K - mu * mu, 0.f);
-      rstd = rsqrtf(var + 1e-5f);
-    }
-    if (row >= R) continue;
-    const float sxr = I8 ? x_scale[row] : 1.f;
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int n = n0 + t * 16 + 4 * g;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= N) continue;
-        float tv = I8 ? (float)acci[a][t][e] * sxr * w_scale[n + e] : acc[a][t][e];
-        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-        else if (bias) tv += (float)bias[n + e];
-        if (act == 1) tv = gelu_erf(tv);
-        if (res) tv += (float)res[(size_t)row * ldr + n + e];
-        if (OUT_F32)
-          reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = tv;
-        else
-          reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)tv;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
 // Skinny GEMM, register-streaming form over FRAGMENT-MAJOR operands (frag_off above).
 //
 // Both the weights (permuted once at pack time) and the activations (written in this order by their
@@ -637,131 +282,124 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_i8_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// Row-loop form of the fragment-major skinny GEMM (experiment, FWAMD_FRAG_ROWLOOP=1; K <= 1280):
-// one workgroup = NT column tiles x ALL row tiles.  Its weight fragments (NT x 10 k-steps per wave) are loaded
-// ONCE and stay in registers while the row tiles are walked two at a time, so a weight byte crosses the fabric
-// exactly once (the tiled form re-fetches it per row group: FETCH_SIZE 10.4 MB vs 6.55 MB algorithmic) at the
-// price of 2.5x fewer, longer workgroups.
+// K16: the vocabulary projection (and any linear with MANY column tiles): full K per wave.
+//
+// Same fragment-major operands as above, but here a wave owns RT row tiles x NT column tiles over the WHOLE K
+// (no split, no reduction, no LDS, no barrier): N = 51 866 gives 3 242 column tiles, so the chip is filled by
+// columns alone.  The K loop is software-pipelined by hand over two register sets of CH k-steps each: the loads
+// of the next set are issued before the MFMAs of the current one.  A workgroup is WM x WN such waves; its waves
+// share the x fragments through the CU's L1.  RT = 5 covers the 80 rows of a 16-chunk x beam-5 step in one wave,
+// so every weight byte is requested exactly once per 80 rows.
+// I8: int8 operands (v_mfma_i32_16x16x64_i8, 64 elements per 16-byte fragment) with per-row scales.
 // ------------------------------------------------------------------------------------
-template <int WAVES, bool LNF, int NT>
-__global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_rowloop_kernel(
-    const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
-    const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
-    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
-  constexpr int RT = 2, PER = 10;
-  __shared__ float red[WAVES][RT * NT][64][4];
-  __shared__ float red_s[WAVES][RT][16][2];
+template <bool I8, bool LNF, bool F32, int RT, int NT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
+    const void* __restrict__ xfv, const float* __restrict__ x_scale, const void* __restrict__ Wfv,
+    const float* __restrict__ w_scale, const half_t* __restrict__ bias, const float* __restrict__ s1,
+    const float* __restrict__ cf, void* __restrict__ outv, int ldo, int R, int N, int K) {
+  constexpr int CH = 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int i = lane & 15, g = lane >> 4;
-  const int ct0 = blockIdx.x * NT;
-  const int n_rt = (R + 15) >> 4;
-  const int KS = K >> 5;
-  const int per = (KS + WAVES - 1) / WAVES;          // <= PER (checked by the launcher)
-  const int ks0 = wave * per;
-  int nks = KS - ks0;
-  if (nks > per) nks = per;
-  if (nks < 0) nks = 0;
-  half8_t wv[NT][PER];
+  const int n_rt = (R + 15) >> 4, n_ct = (N + 15) >> 4;
+  const int rt0 = (blockIdx.y * WM + wm) * RT, ct0 = (blockIdx.x * WN + wn) * NT;
+  if (rt0 >= n_rt || ct0 >= n_ct) return;     // whole waves leave: there is no barrier in this kernel
+  const int KS = K / (I8 ? 64 : 32);
+  const intx4* wp[NT];
+  const intx4* xp[RT];
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
-    const half8_t* wp = reinterpret_cast<const half8_t*>(Wf) + ((size_t)(ct0 + b) * KS + ks0) * 64 + lane;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int jj = j < nks ? j : (nks > 0 ? nks - 1 : 0);
-      wv[b][j] = nks > 0 ? wp[(size_t)jj * 64] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    int ct = ct0 + b; if (ct > n_ct - 1) ct = n_ct - 1;       // a missing tile re-reads the last one; result dropped
+    wp[b] = reinterpret_cast<const intx4*>(Wfv) + (size_t)ct * KS * 64 + lane;
   }
-  for (int rt0 = 0; rt0 < n_rt; rt0 += RT) {
-    floatx4 acc[RT][NT];
-    float rs[RT], rq[RT];
 #pragma unroll
-    for (int a = 0; a < RT; ++a) {
-      rs[a] = 0.f; rq[a] = 0.f;
+  for (int a = 0; a < RT; ++a) {
+    int rt = rt0 + a; if (rt > n_rt - 1) rt = n_rt - 1;
+    xp[a] = reinterpret_cast<const intx4*>(xfv) + (size_t)rt * KS * 64 + lane;
+  }
+  floatx4 accf[RT][NT];
+  intx4 acci[RT][NT];
+  float rs[RT], rq[RT];
 #pragma unroll
-      for (int b = 0; b < NT; ++b) acc[a][b] = floatx4{0, 0, 0, 0};
+  for (int a = 0; a < RT; ++a) {
+    rs[a] = 0.f; rq[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) { accf[a][b] = floatx4{0, 0, 0, 0}; acci[a][b] = intx4{0, 0, 0, 0}; }
+  }
+  struct Set { intx4 w[CH][NT]; intx4 x[CH][RT]; };
+  auto load = [&](Set& f, int ks0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      int ks = ks0 + j; if (ks > KS - 1) ks = KS - 1;        // clamped tail slot: loaded, never multiplied
+#pragma unroll
+      for (int b = 0; b < NT; ++b) f.w[j][b] = wp[b][(size_t)ks * 64];
+#pragma unroll
+      for (int a = 0; a < RT; ++a) f.x[j][a] = xp[a][(size_t)ks * 64];
     }
-    if (nks > 0) {
-      half8_t xv[RT][PER];
+  };
+  auto compute = [&](const Set& f, int ks0) {
 #pragma unroll
-      for (int a = 0; a < RT; ++a) {
-        int rt = rt0 + a;
-        if (rt > n_rt - 1) rt = n_rt - 1;
-        const half8_t* xp = reinterpret_cast<const half8_t*>(xf) + ((size_t)rt * KS + ks0) * 64 + lane;
+    for (int j = 0; j < CH; ++j) {
+      if (ks0 + j < KS) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) xv[a][j] = xp[(size_t)(j < nks ? j : nks - 1) * 64];
-      }
+        for (int a = 0; a < RT; ++a) {
 #pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        if (j < nks) {
+          for (int b = 0; b < NT; ++b) {
+            if (I8) acci[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.w[j][b], f.x[j][a], acci[a][b], 0, 0, 0);
+            else accf[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, f.w[j][b]),
+                                                                    __builtin_bit_cast(half8_t, f.x[j][a]), accf[a][b],
+                                                                    0, 0, 0);
+          }
+          if (LNF) {
+            const half8_t xv = __builtin_bit_cast(half8_t, f.x[j][a]);
+            const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
-          for (int a = 0; a < RT; ++a) {
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[b][j], xv[a][j], acc[a][b], 0, 0, 0);
-            if (LNF) {
-              const half2_t one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const half2_t h2 = {xv[a][j][2 * e], xv[a][j][2 * e + 1]};
-                rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
-                rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
-              }
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h2 = {xv[2 * e], xv[2 * e + 1]};
+              rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
+              rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
             }
           }
         }
       }
     }
+  };
+  Set fa, fb;
+  load(fa, 0);
+  for (int ks0 = 0; ks0 < KS; ks0 += 2 * CH) {
+    load(fb, ks0 + CH);
+    compute(fa, ks0);
+    load(fa, ks0 + 2 * CH);
+    compute(fb, ks0 + CH);
+  }
 #pragma unroll
-    for (int a = 0; a < RT; ++a) {
-      if (LNF) {
-        float sa = rs[a], sb = rq[a];
-        sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-        sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-        if (g == 0) { red_s[wave][a][i][0] = sa; red_s[wave][a][i][1] = sb; }
-      }
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave][a * NT + b][lane][e] = acc[a][b][e];
+  for (int a = 0; a < RT; ++a) {
+    float mu = 0.f, rstd = 1.f;
+    if (LNF) {   // row i of tile a: the 4 k-octet lanes hold the partial sums over the whole K
+      float sa = rs[a], sb = rq[a];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      mu = sa / (float)K;
+      rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
     }
-    __syncthreads();
+    const int row = (rt0 + a) * 16 + i;
+    if (rt0 + a >= n_rt || row >= R) continue;
+    const float sx = I8 ? x_scale[row] : 1.f;
 #pragma unroll
-    for (int a = 0; a < RT; ++a) {
+    for (int b = 0; b < NT; ++b) {
+      if (ct0 + b >= n_ct) continue;
+      const int n = (ct0 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
 #pragma unroll
-      for (int b = 0; b < NT; ++b) {
-        if ((a * NT + b) % WAVES != wave) continue;
-        const int row = (rt0 + a) * 16 + i;
-        if (rt0 + a >= n_rt || row >= R) continue;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += red[w][a * NT + b][lane][e];
-        float mu = 0.f, rstd = 1.f;
-        if (LNF) {
-          float sa = 0.f, sb = 0.f;
-#pragma unroll
-          for (int w = 0; w < WAVES; ++w) { sa += red_s[w][a][i][0]; sb += red_s[w][a][i][1]; }
-          mu = sa / (float)K;
-          rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
-        }
-        const int n = (ct0 + b) * 16 + 4 * g;
-        half4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float tv = v[e];
-          if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-          else if (bias) tv += (float)bias[n + e];
-          if (act == 1) tv = gelu_erf(tv);
-          if (res) tv += (float)res[(size_t)row * ldr + n + e];
-          o[e] = (half_t)tv;
-        }
-        if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
-        if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) continue;
+        float tv = I8 ? (float)acci[a][b][e] * sx * w_scale[n + e] : accf[a][b][e];
+        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
+        else if (bias) tv += (float)bias[n + e];
+        if (F32) reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = tv;
+        else reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)tv;
       }
     }
-    __syncthreads();   // the reduction buffers are rewritten by the next pair of row tiles
   }
 }
 
@@ -1052,13 +690,15 @@ static __device__ __forceinline__ PairMS pair_wave(PairMS a) {
 }
 
 #define LP_NV 56 /* values per thread kept in registers: V <= 56*1024 */
-// counter-based Gumbel noise: murmur3 finaliser of (seed, row, step, token) -> u in (0,1) -> -log(-log u).
+// counter-based Gumbel noise: murmur3 finaliser of (seed, row, step, token) -> u strictly in (0,1) -> -log(-log u).
 // oracle/whisper.py::_gumbel restates the same integer hash.
 static __device__ __forceinline__ float gumbel_noise(unsigned seed_lo, unsigned seed_hi, unsigned row, unsigned step,
                                                      unsigned v) {
   unsigned h = seed_lo ^ (row * 0x9E3779B9u) ^ (step * 0x85EBCA6Bu) ^ (v * 0xC2B2AE35u) ^ (seed_hi * 0x27D4EB2Fu);
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  // 23 bits: (h >> 9) + 0.5 is exact in fp32 for every h, so u stays strictly inside (0, 1) (with 24 bits the
+  // top value rounds to 1.0 and the noise becomes +inf: that token would win whatever its probability)
+  const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
   return -logf(-logf(u));
 }
 __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::GenDev gp, float* __restrict__ logits,
@@ -1415,181 +1055,6 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
   dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, xfrag, d, d_step, pos_fixed, P);
 }
 
-template <int MT, int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool F32>
-static void gemm_go(hipStream_t st, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
-                    const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
-                    int K, int act) {
-  const size_t lds = (size_t)(WAVES * MT * NTW * 256 + WAVES * MT * 16 * 2) * sizeof(float);
-  static bool attr_set = false;  // one flag per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(dec_gemm_kernel<MT, NTW, CH, WAVES, ONESHOT, LNF, F32>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  dec_gemm_kernel<MT, NTW, CH, WAVES, ONESHOT, LNF, F32><<<grid, WAVES * 64, lds, st>>>(x, ldx, W, bias, s1, cf, res, ldr,
-                                                                                   out, ldo, R, N, K, act);
-}
-
-template <int NTW, int CH, int WAVES, bool ONESHOT, bool LNF, bool F32>
-static int gemm_mt(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
-                   const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
-                   int K, int act) {
-#define GO(MT) gemm_go<MT, NTW, CH, WAVES, ONESHOT, LNF, F32>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act)
-  switch (mt) {
-    case 1: GO(1); break;
-    case 2: GO(2); break;
-    case 3: GO(3); break;
-    case 4: GO(4); break;
-    case 5: GO(5); break;
-    default: return -1;
-  }
-#undef GO
-  return 0;
-}
-
-template <int NTW, bool LNF, bool F32>
-static int gemm_k(hipStream_t st, int mt, int grid, const half_t* x, int ldx, const half_t* W, const half_t* bias,
-                  const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K,
-                  int act) {
-#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act
-  // K split over the waves of a workgroup so that a wave's share is <= 5 MFMA k-steps whenever
-  // possible: then ALL loads of the launch are issued at once (one memory latency per GEMM).
-  if (K % 256 == 0 && K / 256 <= 5) return gemm_mt<NTW, 5, 8, true, LNF, F32>(ARGS);    // K <= 1280: 8 waves, one shot
-  if (K % 256 == 0) return gemm_mt<NTW, 4, 8, false, LNF, F32>(ARGS);                   // long K: 8 waves, pipelined
-  if (K / 128 <= 5) return gemm_mt<NTW, 5, 4, true, LNF, F32>(ARGS);                    // small K: 4 waves, one shot
-  return gemm_mt<NTW, 3, 4, false, LNF, F32>(ARGS);
-#undef ARGS
-}
-
-template <int MT, int NTW, int KO, int DEPTH, bool LNF, bool F32, bool I8>
-static void lds_go(hipStream_t st, int grid, const void* x, int ldx, const void* W, const half_t* bias,
-                   const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N,
-                   int K, int act, const float* xs, const float* ws) {
-  constexpr int XPAD = (MT * 16 * (KO + 1) + 255) / 256 * 256, WPAD = (NTW * 16 * (KO + 1) + 255) / 256 * 256;
-  const size_t lds = (size_t)DEPTH * (XPAD + WPAD) * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, F32, I8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  const int groups = ((R + 15) / 16 + MT - 1) / MT;
-  dec_gemm_lds_kernel<MT, NTW, KO, DEPTH, LNF, F32, I8><<<dim3(grid, groups), 256, lds, st>>>(
-      reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<const half_t*>(W), bias, s1, cf, res, ldr, out, ldo, R,
-      N, K, act, xs, ws);
-}
-
-template <int NTW, int KO, int DEPTH, bool LNF, bool F32, bool I8>
-static int lds_mt(hipStream_t st, int mt, int grid, const void* x, int ldx, const void* W, const half_t* bias,
-                  const float* s1, const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K,
-                  int act, const float* xs, const float* ws) {
-#define GO(MT) lds_go<MT, NTW, KO, DEPTH, LNF, F32, I8>(st, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws)
-  switch (mt) {
-    case 1: GO(1); break;
-    case 2: GO(2); break;
-    case 3: GO(3); break;
-    case 4: GO(4); break;
-    case 5: GO(5); break;
-    default: return -1;
-  }
-#undef GO
-  return 0;
-}
-
-// LDS-staged skinny GEMM, fp16 output (the six per-layer decoder linears).
-int launch_dec_gemm_lds(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
-                        const float* cf, const half_t* res, int ldr, half_t* out, int ldo, int R, int N, int K,
-                        int act) {
-  if (K % 128 != 0 || R < 1 || R > 80) return -1;
-  int mt = (R + 15) / 16;
-  const bool lnf = s1 != nullptr;
-  const float* xs = nullptr;
-  const float* ws = nullptr;
-  // tile policy.  "thin" (default): 16/32-column tiles (+ row groups for short N) = many small workgroups,
-  // lowest latency of a single decode stream, and (measured) also the best throughput with 8 batches in
-  // flight (1730 vs 1595).  "fat" (FWAMD_GEMM_TILES=fat): 64-column tiles over all rows = 3x less L2->LDS
-  // re-read of the activations in total, at the price of fewer, longer workgroups.
-  static const int fat = [] { const char* e = getenv("FWAMD_GEMM_TILES"); return (e && e[0] == 'f') ? 1 : 0; }();
-  if (fat && K % 160 == 0 && N >= 64) {
-    const int grid = (N + 63) / 64;
-#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws
-    return lnf ? lds_mt<4, 20, 2, true, false, false>(ARGS) : lds_mt<4, 20, 2, false, false, false>(ARGS);
-#undef ARGS
-  }
-  if (N <= 2048 && mt > 2) mt = 2;   // short N: 2 row tiles per workgroup, row groups on grid.y
-  // experiment knobs (profiles/README.md): FWAMD_GEMM_MT caps the row tiles per workgroup for every N
-  // (more, smaller workgroups per CU), FWAMD_GEMM_DEPTH=4 deepens the ring where it still fits in LDS
-  static const int env_mt = [] { const char* e = getenv("FWAMD_GEMM_MT"); return e ? atoi(e) : 0; }();
-  static const int env_depth = [] { const char* e = getenv("FWAMD_GEMM_DEPTH"); return e ? atoi(e) : 2; }();
-  static const int env_ntw = [] { const char* e = getenv("FWAMD_GEMM_NTW"); return e ? atoi(e) : 0; }();
-  if (env_mt >= 1 && env_mt <= 5 && mt > env_mt) mt = env_mt;
-  int ntw = (N <= 4096) ? 1 : 2;
-  if (env_ntw == 1 || env_ntw == 2) ntw = env_ntw;
-  const int grid = (N + 16 * ntw - 1) / (16 * ntw);
-#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, xs, ws
-  // 160-wide slices through a 2-slot ring (<= 82 KB of LDS: two workgroups, e.g. of two worker replicas,
-  // fit a CU).  Measured: a 4-slot ring is 11 % faster single-stream (1036 vs 926) but 8 % slower with 8
-  // batches in flight (1516 vs 1637), and throughput is what the metric counts.
-  if (K % 160 == 0) {
-    const int slot = (((mt * 16 * 21 + 255) / 256) + ((ntw * 16 * 21 + 255) / 256)) * 256 * 16;
-    if (env_depth == 4 && 4 * slot <= 160 * 1024) {
-      if (ntw == 1) return lnf ? lds_mt<1, 20, 4, true, false, false>(ARGS) : lds_mt<1, 20, 4, false, false, false>(ARGS);
-      return lnf ? lds_mt<2, 20, 4, true, false, false>(ARGS) : lds_mt<2, 20, 4, false, false, false>(ARGS);
-    }
-    if (ntw == 1) return lnf ? lds_mt<1, 20, 2, true, false, false>(ARGS) : lds_mt<1, 20, 2, false, false, false>(ARGS);
-    return lnf ? lds_mt<2, 20, 2, true, false, false>(ARGS) : lds_mt<2, 20, 2, false, false, false>(ARGS);
-  }
-  if (ntw == 1) return lnf ? lds_mt<1, 16, 2, true, false, false>(ARGS) : lds_mt<1, 16, 2, false, false, false>(ARGS);
-  return lnf ? lds_mt<2, 16, 2, true, false, false>(ARGS) : lds_mt<2, 16, 2, false, false, false>(ARGS);
-#undef ARGS
-}
-
-// int8 x int8 skinny GEMM (int8_float16 path): xq [R][K] int8 + x_scale[R], Wq [N][K] int8 + w_scale[N].
-// fp16 output (out_f32 = false) or float32 (logits).
-int launch_dec_gemm_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq, const float* w_scale,
-                       const half_t* bias, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
-                       bool out_f32) {
-  if (K % 128 != 0 || R < 1 || R > 80 || !x_scale || !w_scale) return -1;
-  int mt = (R + 15) / 16;
-  if (N <= 2048 && mt > 2) mt = 2;
-  const int ntw = (N <= 4096) ? 1 : 2;
-  const int grid = (N + 16 * ntw - 1) / (16 * ntw);
-  const float* s1 = nullptr;
-  const float* cf = nullptr;
-  const int ldx = K;
-  const void* x = xq;
-  const void* W = Wq;
-#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act, x_scale, w_scale
-  if (K % 320 == 0) {   // 16 int8 per 16-byte piece: a 20-piece slice covers 320 elements
-    if (out_f32) return ntw == 1 ? lds_mt<1, 20, 2, false, true, true>(ARGS) : lds_mt<2, 20, 2, false, true, true>(ARGS);
-    return ntw == 1 ? lds_mt<1, 20, 2, false, false, true>(ARGS) : lds_mt<2, 20, 2, false, false, true>(ARGS);
-  }
-  if (out_f32) return ntw == 1 ? lds_mt<1, 8, 2, false, true, true>(ARGS) : lds_mt<2, 8, 2, false, true, true>(ARGS);
-  return ntw == 1 ? lds_mt<1, 8, 2, false, false, true>(ARGS) : lds_mt<2, 8, 2, false, false, true>(ARGS);
-#undef ARGS
-}
-
-// x [R][ldx] fp16 (raw residual stream when s1/cf are given = LayerNorm folded), W [N][K] fp16.
-int launch_dec_gemm(hipStream_t st, const half_t* x, int ldx, const half_t* W, const half_t* bias, const float* s1,
-                    const float* cf, const half_t* res, int ldr, void* out, int ldo, int R, int N, int K, int act,
-                    bool out_f32) {
-  if (K % 128 != 0 || R < 1 || R > 80) return -1;
-  const int mt = (R + 15) / 16;
-  const bool lnf = s1 != nullptr;
-  // columns per workgroup: 16 keeps more workgroups in flight, 32 halves the L2->L1 re-read of x
-  const int ntw = (N <= 4096) ? 1 : 2;
-  const int grid = (N + 16 * ntw - 1) / (16 * ntw);
-#define ARGS st, mt, grid, x, ldx, W, bias, s1, cf, res, ldr, out, ldo, R, N, K, act
-  if (out_f32) {
-    if (!lnf) return -1;
-    return ntw == 2 ? gemm_k<2, true, true>(ARGS) : gemm_k<1, true, true>(ARGS);
-  }
-  if (lnf) return ntw == 2 ? gemm_k<2, true, false>(ARGS) : gemm_k<1, true, false>(ARGS);
-  return ntw == 2 ? gemm_k<2, false, false>(ARGS) : gemm_k<1, false, false>(ARGS);
-#undef ARGS
-}
-
 template <bool LNF, int RT, int NT>
 static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N,
@@ -1603,58 +1068,62 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
                                                                K, act);
 }
 
-// Register-streaming skinny GEMM over fragment-major x / W (see dec_gemm_frag_kernel).  out (row-major) and
-// out_frag (fragment-major, for the next GEMM) are both optional; res is row-major.
-// Knobs: FWAMD_FRAG_RT / FWAMD_FRAG_NT = 1 | 2 (row / column tiles per workgroup), FWAMD_FRAG_WAVES = 4 | 8.
+// The per-layer decoder linears: K split over the waves of a workgroup, 2 x 2 tiles of 16 x 16 per workgroup
+// (measured best of {1,2} x {1,2}: profiles/r01_sweep_dec_gemm_frag_tiles.jsonl), row groups on grid.y so any
+// number of rows works (a merged decode run carries up to 128 chunks x 5 beams).  out (row-major) and out_frag
+// (fragment-major, for the next GEMM) are both optional; res is row-major.
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act) {
-  if (K % 32 != 0 || N % 32 != 0 || R < 1 || R > 80) return -1;
-  // default 2 x 2 tiles (32 rows x 32 columns per workgroup): measured 1255x single stream / 2102x with 8 batches
-  // in flight, against 1278x / 1957x for 1 x 1 (profiles/r01_sweep_dec_gemm_frag_tiles.jsonl)
-  static const int env_rt = [] { const char* e = getenv("FWAMD_FRAG_RT"); return (e && e[0] == '1') ? 1 : 2; }();
-  static const int env_nt = [] { const char* e = getenv("FWAMD_FRAG_NT"); return (e && e[0] == '1') ? 1 : 2; }();
-  static const int env_w = [] { const char* e = getenv("FWAMD_FRAG_WAVES"); return e ? atoi(e) : 0; }();
-  const int waves = (env_w == 4 || env_w == 8) ? env_w : (K >= 2560 ? 8 : 4);
-  const bool lnf = s1 != nullptr;
-  // experiment (profiles/README.md): row-loop form, weights cross the fabric once; needs K/32/waves <= 10
-  static const bool rowloop = [] { const char* e = getenv("FWAMD_FRAG_ROWLOOP"); return e && e[0] == '1'; }();
-  if (rowloop && ((K >> 5) + waves - 1) / waves <= 10 && N % 32 == 0) {
-    const dim3 grid(N / 32, 1);
-    if (waves == 8) {
-      if (lnf) dec_gemm_frag_rowloop_kernel<8, true, 2><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-      else dec_gemm_frag_rowloop_kernel<8, false, 2><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    } else {
-      if (lnf) dec_gemm_frag_rowloop_kernel<4, true, 2><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-      else dec_gemm_frag_rowloop_kernel<4, false, 2><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    }
-    return 0;
-  }
-#define FG(L, A, B) frag_go<L, A, B>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
-  // the long-K linear (ffn2, K = 4d) walks its k-steps in several chunks of 20/(RT+NT): its tile shape can be set
-  // apart (FWAMD_FRAG_LONGK_RT / _NT = 1 | 2, default: same as the others) — experiment knob
-  static const int lk_rt = [] { const char* e = getenv("FWAMD_FRAG_LONGK_RT"); return e ? (e[0] == '1' ? 1 : 2) : 0; }();
-  static const int lk_nt = [] { const char* e = getenv("FWAMD_FRAG_LONGK_NT"); return e ? (e[0] == '1' ? 1 : 2) : 0; }();
-  const int use_rt = (K >= 2560 && lk_rt) ? lk_rt : env_rt;
-  const int use_nt = (K >= 2560 && lk_nt) ? lk_nt : env_nt;
-  if (use_rt == 2 && use_nt == 2) { if (lnf) FG(true, 2, 2); else FG(false, 2, 2); }
-  else if (use_rt == 2) { if (lnf) FG(true, 2, 1); else FG(false, 2, 1); }
-  else if (use_nt == 2) { if (lnf) FG(true, 1, 2); else FG(false, 1, 2); }
-  else { if (lnf) FG(true, 1, 1); else FG(false, 1, 1); }
-#undef FG
+  if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
+  const int waves = K >= 2560 ? 8 : 4;   // keeps a wave's share at <= 20 k-steps = 2 chunks of loads
+  if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
   return 0;
 }
 
-// int8 fragment-major skinny GEMM (see dec_gemm_frag_i8_kernel); xq / Wq fragment-major, out row-major fp16
+// int8 form (see dec_gemm_frag_i8_kernel); xq / Wq fragment-major, out row-major fp16
 int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq,
                             const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
                             int R, int N, int K, int act) {
-  if (K % 64 != 0 || N % 32 != 0 || R < 1 || R > 80 || !x_scale || !w_scale) return -1;
+  if (K % 64 != 0 || N % 32 != 0 || R < 1 || !x_scale || !w_scale) return -1;
   const dim3 grid(N / 32, ((R + 15) / 16 + 1) / 2);
   if (K >= 2560)
     dec_gemm_frag_i8_kernel<8, 2, 2><<<grid, 512, 0, st>>>(xq, x_scale, Wq, w_scale, bias, res, ldr, out, ldo, R, N, K, act);
   else
     dec_gemm_frag_i8_kernel<4, 2, 2><<<grid, 256, 0, st>>>(xq, x_scale, Wq, w_scale, bias, res, ldr, out, ldo, R, N, K, act);
+  return 0;
+}
+
+template <bool I8, bool LNF, int RT>
+static void wave_go(hipStream_t st, const void* xf, const float* x_scale, const void* Wf, const float* w_scale,
+                    const float* s1, const float* cf, float* out, int ldo, int R, int N, int K) {
+  constexpr int NT = 2, WM = 1, WN = 4;
+  const int n_rt = (R + 15) / 16, n_ct = (N + 15) / 16;
+  const dim3 grid((n_ct + NT * WN - 1) / (NT * WN), (n_rt + RT * WM - 1) / (RT * WM));
+  dec_gemm_wave_kernel<I8, LNF, true, RT, NT, WM, WN><<<grid, WM * WN * 64, 0, st>>>(xf, x_scale, Wf, w_scale, nullptr, s1,
+                                                                                     cf, out, ldo, R, N, K);
+}
+
+// Vocabulary projection -> float32 logits [R][ldo].  fp16: xf = the raw residual stream, fragment-major, with the
+// final LayerNorm folded into Wf / s1 / cf.  int8: xf = the LayerNorm'ed rows quantised per row (x_scale),
+// Wf int8 + w_scale.  Wf holds ceil(N / 16) fragment-major column tiles (the last one zero-padded).
+int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_scale, const void* Wf,
+                      const float* w_scale, const float* s1, const float* cf, float* out, int ldo, int R, int N, int K) {
+  if (K % (i8 ? 64 : 32) != 0 || R < 1) return -1;
+  if (i8 ? (!x_scale || !w_scale) : (!s1 || !cf)) return -1;
+  const int n_rt = (R + 15) / 16;
+#define WG(RT)                                                                                   \
+  do {                                                                                           \
+    if (i8) wave_go<true, false, RT>(st, xf, x_scale, Wf, w_scale, s1, cf, out, ldo, R, N, K);   \
+    else wave_go<false, true, RT>(st, xf, x_scale, Wf, w_scale, s1, cf, out, ldo, R, N, K);      \
+  } while (0)
+  if (n_rt == 1) WG(1);
+  else if (n_rt == 2) WG(2);
+  else if (n_rt == 3) WG(3);
+  else if (n_rt == 4) WG(4);
+  else WG(5);   // 5 row tiles = the 80 rows of a 16-chunk beam-5 step per wave; more rows: row groups on grid.y
+#undef WG
   return 0;
 }
 
@@ -1667,12 +1136,8 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag) {
-  // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup; FWAMD_CA_WAVES=4 halves that
-  static const int waves = [] { const char* e = getenv("FWAMD_CA_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
-  if (waves == 4)
-    dec_cross_attn_kernel<4><<<dim3(H, B), 256, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
-  else
-    dec_cross_attn_kernel<8><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
+  // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup (4 waves measured slower)
+  dec_cross_attn_kernel<8><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {

@@ -8,6 +8,14 @@
 //   ctranslate2.models.Whisper.align            :1709-1715
 // The decoding rules restate CTranslate2 4.x / openai-whisper behaviour (SURVEY.md
 // Appendix A); oracle/whisper.py is the CPU statement of the same rules.
+//
+// Decode groups.  A decode step is HBM-bound: it streams every decoder weight once (1.47 GB for large-v3)
+// whatever the number of rows.  CTranslate2 runs `inter_threads` replicas side by side, each streaming the weights
+// for its own batch; here the worker replicas of a device share ONE decode workspace sized for all of their
+// batches (288 GB of HBM make that cheap), and fw_generate calls that arrive while a run is in progress are
+// merged into the next run: up to decode_batch chunks x beam rows share each weight byte and each launch.  The
+// encoders of the other workers overlap with the running decode on their own streams (MFMA-bound next to
+// HBM-bound).  Results are independent of the merge: every kernel works per row / per chunk.
 #include "engine.h"
 
 #include <math.h>
@@ -16,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <numeric>
 
 #include "dec_kernels.h"
@@ -26,15 +35,23 @@ namespace fw {
 using fwd::FIN_CAP;
 using fwd::GenDev;
 
+struct GraphSlot {
+  hipGraphExec_t exec = nullptr;
+  GenDev key;
+  uint64_t stamp = 0;
+};
+
 struct GenWorkspace {
-  int B = 0, K = 0, R = 0, NT = 0;
+  int B = 0, K = 0, R = 0, NT = 0;       // capacity: chunks, beams per chunk, rows = B * K
+  int EB = 0;                            // chunks of one encoder output (the models' max_batch)
   int kvp = 0;                           // encoder positions padded to the 32-key MFMA group
   half_t *ck = nullptr, *cvt = nullptr;  // cross K / V^T [L][B][H][kvp*64], MFMA-fragment-major (dec_kernels.hip K14)
-  uint64_t ckv_id = 0;                   // id of the encoder output the cross K/V belong to
+  std::vector<uint64_t> slot_enc;        // per chunk slot: id of the encoder output whose K/V it holds (0 = none)
+  std::vector<int> slot_chunk;           //                 and which chunk of it
   half_t *sk = nullptr, *sv = nullptr;   // [L][R][H][NT][64]
-  half_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
+  half_t *x = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
   float* logits = nullptr;               // [R][V]
-  int* prompt_dev = nullptr;             // [NT][B]
+  int* prompt_dev = nullptr;             // [NT][max(R, B)]
   int* cur_tok = nullptr;                // [R]
   int* hist2 = nullptr;                  // [2][R][NT]
   float* cum2 = nullptr;                 // [2][R]
@@ -46,63 +63,82 @@ struct GenWorkspace {
   int* d_step = nullptr;
   float* no_speech = nullptr;
   uint8_t* sup_mask = nullptr;
-  int* zero_done = nullptr;              // [B] zeros (kernels that take a `done` pointer outside generate)
-  half_t *x_frag = nullptr, *att_frag = nullptr, *ffn_frag = nullptr;   // fragment-major GEMM inputs (dec_frag)
-  int8_t* xq = nullptr;                  // int8_float16: quantised linear input [R][4d]
+  int* zero_done = nullptr;              // [R] zeros (kernels that take a `done` pointer outside generate)
+  half_t *x_frag = nullptr, *att_frag = nullptr, *ffn_frag = nullptr;   // fragment-major GEMM inputs (fp16)
+  int8_t* xq = nullptr;                  // int8_float16: quantised linear input, fragment-major [R16][4d]
   float* xs = nullptr;                   //               per-row de-quantisation scale [R]
-  // graph cache for the decode step
-  hipGraphExec_t graph = nullptr;
-  GenDev graph_key;
-  bool graph_valid = false;
+  int8_t* ekq = nullptr;                 // int8_float16: one encoder output quantised for the cross-K/V projection
+  float* eks = nullptr;
+  // hipGraphs of the decode step, one per distinct GenDev (merged runs differ in their chunk count)
+  std::vector<GraphSlot> graphs;
+  uint64_t graph_clock = 0;
   bool graphs_enabled = true;
 };
 
 static std::atomic<uint64_t> g_tensor_id{1};
 uint64_t next_tensor_id() { return g_tensor_id.fetch_add(1); }
 
-int gen_workspace_create(Model* m) {
+int64_t gen_workspace_bytes(const Model* m, int decode_batch) {
+  const fw_config& c = m->cfg;
+  const int64_t B = decode_batch, R = B * m->max_beam, d = c.d_model, L = c.n_dec_layers, NT = c.n_text_ctx;
+  const int64_t kvp = ((c.n_audio_ctx + 31) / 32) * 32;
+  int64_t n = 2 * (L * B * d * kvp) * 2 + 2 * (L * R * NT * d) * 2;   // cross K/V^T, self K/V (fp16)
+  n += R * (int64_t)c.n_vocab * 4 + R * 12 * d * 2 * 2;                // logits, activations
+  n += R * FIN_CAP * NT * 4 + 3 * R * NT * 4;                          // finished hypotheses, histories
+  return n + (64 << 20);
+}
+
+int gen_workspace_ensure(Model* m) {
+  if (m->gen) return FW_OK;
   const fw_config& c = m->cfg;
   GenWorkspace* g = new GenWorkspace();
   m->gen = g;
-  g->B = m->max_batch;
+  if (m->decode_batch < m->max_batch) m->decode_batch = m->max_batch;
+  g->B = m->decode_batch;
+  g->EB = m->max_batch;
   g->K = m->max_beam;
   g->R = g->B * g->K;
   g->NT = c.n_text_ctx;
   g->kvp = ((c.n_audio_ctx + 31) / 32) * 32;
-  const size_t B = g->B, R = g->R, d = c.d_model, T = c.n_audio_ctx, L = c.n_dec_layers, NT = g->NT;
-  const size_t Rg = std::max<size_t>(R, B);
-  FW_CHECK_ARG(R <= 80, "max_batch * max_beam must be <= 80 (got %zu)", R);
+  g->slot_enc.assign(g->B, 0);
+  g->slot_chunk.assign(g->B, 0);
+  const size_t B = g->B, R = g->R, d = c.d_model, L = c.n_dec_layers, NT = g->NT;
+  FW_CHECK_ARG(R <= 2048, "decode_batch * max_beam must be <= 2048 (got %zu)", R);
+  FW_HIP(hipSetDevice(m->device));
+  if (!m->dec_stream) FW_HIP(hipStreamCreateWithFlags(&m->dec_stream, hipStreamNonBlocking));
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
   A(g->ck, L * B * d * g->kvp);
   A(g->cvt, L * B * d * g->kvp);
   A(g->sk, L * R * NT * d);
   A(g->sv, L * R * NT * d);
-  A(g->x, Rg * d); A(g->xn, Rg * d); A(g->qkv, Rg * 3 * d); A(g->att, Rg * d); A(g->qc, Rg * d);
-  A(g->ffn, Rg * 4 * d);
-  A(g->logits, Rg * c.n_vocab);
-  A(g->prompt_dev, NT * Rg);
-  A(g->cur_tok, Rg);
+  A(g->x, R * d); A(g->qkv, R * 3 * d); A(g->att, R * d); A(g->qc, R * d);
+  A(g->ffn, R * 4 * d);
+  A(g->logits, R * c.n_vocab);
+  A(g->prompt_dev, NT * R);
+  A(g->cur_tok, R);
   A(g->hist2, 2 * R * NT);
   A(g->cum2, 2 * R);
   A(g->kvidx2, 2 * R * NT);
   A(g->cand_val, R * 32);
   A(g->cand_tok, R * 32);
   // per-chunk state is sized by ROWS: random sampling runs every hypothesis as its own beam-1 chunk
-  A(g->done, Rg); A(g->n_done, 1); A(g->n_fin, Rg);
-  A(g->fin_tok, Rg * FIN_CAP * NT); A(g->fin_len, Rg * FIN_CAP);
-  A(g->fin_score, Rg * FIN_CAP); A(g->fin_cum, Rg * FIN_CAP);
+  A(g->done, R); A(g->n_done, 1); A(g->n_fin, R);
+  A(g->fin_tok, R * FIN_CAP * NT); A(g->fin_len, R * FIN_CAP);
+  A(g->fin_score, R * FIN_CAP); A(g->fin_cum, R * FIN_CAP);
   A(g->d_step, 1);
-  A(g->no_speech, Rg);
+  A(g->no_speech, R);
   A(g->sup_mask, (size_t)c.n_vocab);
-  A(g->zero_done, Rg);
+  A(g->zero_done, R);
+  const size_t R16 = (R + 15) / 16 * 16;   // whole 16-row tiles
   if (m->compute_type == FW_COMPUTE_INT8_FLOAT16) {
-    A(g->xq, (Rg + 15) / 16 * 16 * 4 * d);   // whole 16-row tiles (fragment-major form)
-    A(g->xs, Rg);
-    FW_HIP(hipMemset(g->xq, 0, (Rg + 15) / 16 * 16 * 4 * d));
-  }
-  if (m->dec_frag) {
-    const size_t R16 = (Rg + 15) / 16 * 16;   // whole 16-row tiles
+    A(g->xq, R16 * 4 * d);
+    A(g->xs, R16);
+    FW_HIP(hipMemset(g->xq, 0, R16 * 4 * d));
+    FW_HIP(hipMemset(g->xs, 0, R16 * sizeof(float)));
+    A(g->ekq, (size_t)g->EB * c.n_audio_ctx * d);
+    A(g->eks, (size_t)g->EB * c.n_audio_ctx);
+  } else {
     A(g->x_frag, R16 * d); A(g->att_frag, R16 * d); A(g->ffn_frag, R16 * 4 * d);
     FW_HIP(hipMemset(g->x_frag, 0, R16 * d * sizeof(half_t)));
     FW_HIP(hipMemset(g->att_frag, 0, R16 * d * sizeof(half_t)));
@@ -112,9 +148,10 @@ int gen_workspace_create(Model* m) {
   // the padded keys (>= T) are never written: K garbage is masked, V^T must be 0 (0 * NaN)
   FW_HIP(hipMemset(g->ck, 0, L * B * d * g->kvp * sizeof(half_t)));
   FW_HIP(hipMemset(g->cvt, 0, L * B * d * g->kvp * sizeof(half_t)));
-  FW_HIP(hipMemset(g->zero_done, 0, Rg * sizeof(int)));
+  FW_HIP(hipMemset(g->zero_done, 0, R * sizeof(int)));
   FW_HIP(hipMemset(g->d_step, 0, sizeof(int)));
-  const char* ng = getenv("FWAMD_NO_GRAPH");
+  FW_HIP(hipDeviceSynchronize());
+  const char* ng = getenv("FWAMD_NO_GRAPH");   // rocprofv3 7.2 crashes on replayed graphs: profile eagerly
   g->graphs_enabled = !(ng && ng[0] == '1');
   return FW_OK;
 }
@@ -122,47 +159,57 @@ int gen_workspace_create(Model* m) {
 void gen_workspace_free(Model* m) {
   GenWorkspace* g = m->gen;
   if (!g) return;
-  if (g->graph) (void)hipGraphExecDestroy(g->graph);
-  void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->xn, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
+  for (GraphSlot& s : g->graphs)
+    if (s.exec) (void)hipGraphExecDestroy(s.exec);
+  void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_mask,
-                  g->zero_done, g->xq, g->xs, g->x_frag, g->att_frag, g->ffn_frag};
+                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
   m->gen = nullptr;
 }
 
-// K11: cross-attention K / V^T of every decoder layer for this encoder output (once per batch)
-static int ensure_cross_kv(Model* m, const Tensor* enc) {
+// K11: cross-attention K / V^T of every decoder layer for the chunks of one encoder output, written to the
+// chunk slots [b0, b0 + enc->B) of the decode workspace (once per generate call)
+static int ensure_cross_kv(Model* m, const Tensor* enc, int b0) {
   GenWorkspace* g = m->gen;
-  if (g->ckv_id == enc->id) return FW_OK;
+  const int B = enc->B;
+  bool hit = true;
+  for (int i = 0; i < B; ++i) hit = hit && g->slot_enc[b0 + i] == enc->id && g->slot_chunk[b0 + i] == i;
+  if (hit) return FW_OK;
+  // a failure half way leaves the slots marked empty, never pointing at partly overwritten K/V
+  for (int i = 0; i < B; ++i) g->slot_enc[b0 + i] = 0;
   const fw_config& c = m->cfg;
-  const int d = c.d_model, T = c.n_audio_ctx, B = enc->B;
+  const int d = c.d_model, T = c.n_audio_ctx;
   const int64_t xs = (int64_t)T * d;
+  hipStream_t st = m->dec_stream;
   int rc;
-  ProfScope ps(m, PF_CROSS_KV_GEMM, 2.0 * c.n_dec_layers * B * (double)T * d * (2.0 * d), 0);
+  ProfScope ps(m, PF_CROSS_KV_GEMM, 2.0 * c.n_dec_layers * B * (double)T * d * (2.0 * d), 0, st);
   const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   const int kvp = g->kvp;
   const int64_t kvs = (int64_t)d * kvp;   // one chunk's K (or V^T): H heads x kvp keys x 64
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
-    half_t* kd = g->ck + (size_t)l * g->B * kvs;
-    half_t* vd = g->cvt + (size_t)l * g->B * kvs;
+    half_t* kd = g->ck + ((size_t)l * g->B + b0) * kvs;
+    half_t* vd = g->cvt + ((size_t)l * g->B + b0) * kvs;
     // both land in the MFMA-fragment-major layout of the decode kernel (head_rows = kvp selects it in the
     // GEMM epilogue): K through the plain epilogue, V^T through the transposed one
     if (i8) {
       // the encoder output is quantised once (layer 0) and shared by all 2L projections
       if ((rc = run_linear_i8(m, L.ck, l == 0 ? enc->data : nullptr, nullptr, kd, d, kvs, nullptr, 0, 0, T, B, 0,
-                              false, kvp)))
+                              false, kvp, st, g->ekq, g->eks)))
         return rc;
-      if ((rc = run_linear_i8(m, L.cv, nullptr, nullptr, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp))) return rc;
+      if ((rc = run_linear_i8(m, L.cv, nullptr, nullptr, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp, st, g->ekq,
+                              g->eks)))
+        return rc;
       continue;
     }
-    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, kvs, nullptr, 0, 0, T, B, 0, false, kvp))) return rc;
-    if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp))) return rc;
+    if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, kvs, nullptr, 0, 0, T, B, 0, false, kvp, st))) return rc;
+    if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp, st))) return rc;
   }
-  g->ckv_id = enc->id;
+  for (int i = 0; i < B; ++i) { g->slot_enc[b0 + i] = enc->id; g->slot_chunk[b0 + i] = i; }
   return FW_OK;
 }
 
@@ -176,7 +223,6 @@ struct StepCfg {
   int nospeech_rowmul; // > 0: run the no-speech kernel on rows b*rowmul after the logits GEMM
   bool beam_tail;      // logits rules + beam update + step advance
   const int* done;     // per-chunk done flags for cross-attn early exit
-  int kv_div = 1;      // decode chunks per encoder chunk (sampling: num_hypotheses)
   // align extras
   const int* sel_heads_dev = nullptr;   // [n_sel_total] head ids, grouped per layer
   const int* sel_layer_off = nullptr;   // host: [L+1] offsets into sel_heads
@@ -191,48 +237,34 @@ struct StepCfg {
     }                                                                   \
   } while (0)
 
+// One decoder forward over `rows` rows.  Everything that varies from step to step lives in HBM (d_step, beam
+// tables), and everything a captured graph bakes in by value is part of GenDev (the graph key).
 static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   GenWorkspace* g = m->gen;
   const fw_config& c = m->cfg;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, NT = g->NT;
-  hipStream_t st = m->stream;
+  hipStream_t st = m->dec_stream;
   const int rows = s.rows;
-  const double wbytes_layer = 2.0 * (12.0 * d * d);  // fp16 bytes of one layer's linears (3+1+1+1+4+4 = 14? see below)
-  (void)wbytes_layer;
+  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   {
-    ProfScope ps(m, PF_DEC_MISC, 0, 0);
-    fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, m->dec_frag ? g->x_frag : nullptr, rows, d, g->d_step,
+    ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
+    fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, i8 ? nullptr : g->x_frag, rows, d, g->d_step,
                       s.pos_fixed, s.P);
   }
-  // one decoder linear: x[rows][K] -> out[rows][N]; LayerNorm-folded when L.s1 is set; in-place residual
-  static const bool use_lds_gemm = !(getenv("FWAMD_REG_GEMM") && getenv("FWAMD_REG_GEMM")[0] == '1');
-  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
-  // int8_float16 (K25): the row quantiser (fused with the LayerNorm where one feeds the linear) runs as its
-  // own tiny kernel, then the int8 skinny GEMM de-quantises in its epilogue
+  // int8_float16 (K25): the row quantiser (fused with the LayerNorm where one feeds the linear) writes the int8
+  // rows fragment-major, then the int8 skinny GEMM de-quantises in its epilogue
   auto lin_q = [&](const half_t* xin, const LNW* ln, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
-    if (m->dec_frag_i8) {   // opt-in: fragment-major int8 operands, register-streaming kernel
-      fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K, 1);
-      return fwd::launch_dec_gemm_frag_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K,
-                                          act);
-    }
-    fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K);
-    return fwd::launch_dec_gemm_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K, act,
-                                   false);
+    fwk::launch_quant_rows(st, xin, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, g->xq, g->xs, rows, L.K, 1);
+    return fwd::launch_dec_gemm_frag_i8(st, g->xq, g->xs, L.wq, L.wscale, L.b, res, L.N, outp, L.N, rows, L.N, L.K, act);
   };
-  // fragment-major flow (m->dec_frag, fp16): xin is the fragment-major copy of the input; the residual stream is
-  // kept row-major too (logits GEMM, residual adds), the FFN hidden only fragment-major
-  const bool frag = m->dec_frag;
+  // fp16: xin is the fragment-major copy of the input; the residual stream is kept row-major too (residual
+  // adds), the FFN hidden only fragment-major; LayerNorms are folded into qkv / cross-q / ffn1
   auto lin_f = [&](const half_t* xin_frag, const LinearW& L, const half_t* res, half_t* outp, half_t* outp_frag,
                    int act) -> int {
     return fwd::launch_dec_gemm_frag(st, xin_frag, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, outp_frag, rows, L.N,
                                      L.K, act);
   };
-  auto lin = [&](const half_t* xin, const LNW* ln, const LinearW& L, const half_t* res, half_t* outp, int act) -> int {
-    if (i8) return lin_q(xin, ln, L, res, outp, act);
-    if (use_lds_gemm)
-      return fwd::launch_dec_gemm_lds(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act);
-    return fwd::launch_dec_gemm(st, xin, L.K, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, rows, L.N, L.K, act, false);
-  };
+  const int frag = i8 ? 0 : 1;
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
     half_t* kc = g->sk + (size_t)l * g->R * NT * d;
@@ -240,69 +272,69 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     const half_t* ck = g->ck + (size_t)l * g->B * d * g->kvp;
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * g->kvp;
     {
-      ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d);
-      if (frag) DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
-      else DG(lin(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
+      ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d, st);
+      if (i8) DG(lin_q(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
+      else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
     }
     {
-      ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0);
+      ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0, st);
       fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, H, g->kvidx2, gp.K, s.kmul, frag ? g->att_frag : g->att, rows,
-                            g->d_step, s.pos_fixed, s.P, gp.R, frag ? 1 : 0);
+                            g->d_step, s.pos_fixed, s.P, gp.R, frag);
     }
     {
-      ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d);
-      if (frag) {
+      ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d, st);
+      if (i8) {
+        DG(lin_q(g->att, nullptr, L.out, g->x, g->x, 0));
+        DG(lin_q(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
+      } else {
         DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0));
         DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0));
-      } else {
-        DG(lin(g->att, nullptr, L.out, g->x, g->x, 0));
-        DG(lin(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
       }
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
-      ProfScope ps(m, PF_DEC_MISC, 0, 0);
+      ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
       const int off = s.sel_layer_off[l], n = s.sel_layer_off[l + 1] - off;
       fwd::launch_cross_probs(st, g->qc, d, ck, T, g->kvp, s.sel_heads_dev + off, n, s.n_sel_total,
                               s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
     }
     {
-      ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * s.B * (double)T * d);
+      ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * (s.B / gp.kv_div) * (double)T * d, st);
       fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, g->kvp, s.kmul, frag ? g->att_frag : g->att, s.B, H, s.done,
-                             s.kv_div, frag ? 1 : 0);
+                             gp.kv_div, frag);
     }
     {
-      ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d);
-      if (frag) DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0));
-      else DG(lin(g->att, nullptr, L.cout, g->x, g->x, 0));
+      ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d, st);
+      if (i8) DG(lin_q(g->att, nullptr, L.cout, g->x, g->x, 0));
+      else DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0));
     }
     {
-      ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      if (frag) DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
-      else DG(lin(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
+      ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
+      if (i8) DG(lin_q(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
+      else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
     }
     {
-      ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d);
-      if (frag) DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0));
-      else DG(lin(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
+      ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
+      if (i8) DG(lin_q(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
+      else DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0));
     }
   }
   if (s.need_logits || s.beam_tail) {
-    ProfScope ps(m, PF_DEC_LOGITS, 2.0 * rows * (double)c.n_vocab * d, 2.0 * c.n_vocab * d);
+    ProfScope ps(m, PF_DEC_LOGITS, 2.0 * rows * (double)c.n_vocab * d, 2.0 * c.n_vocab * d, st);
     if (i8) {
-      fwk::launch_quant_rows(st, g->x, d, m->dec_ln.g, m->dec_ln.b, g->xq, g->xs, rows, d);
-      DG(fwd::launch_dec_gemm_i8(st, g->xq, g->xs, m->logits.wq, m->logits.wscale, nullptr, nullptr, 0, g->logits,
-                                 c.n_vocab, rows, c.n_vocab, d, 0, true));
+      fwk::launch_quant_rows(st, g->x, d, m->dec_ln.g, m->dec_ln.b, g->xq, g->xs, rows, d, 1);
+      DG(fwd::launch_dec_logits(st, true, g->xq, g->xs, m->logits.wq, m->logits.wscale, nullptr, nullptr, g->logits,
+                                c.n_vocab, rows, c.n_vocab, d));
     } else {
-      DG(fwd::launch_dec_gemm(st, g->x, d, m->logits.w, nullptr, m->logits.s1, m->logits.cf, nullptr, 0, g->logits,
-                              c.n_vocab, rows, c.n_vocab, d, 0, true));
+      DG(fwd::launch_dec_logits(st, false, g->x_frag, nullptr, m->logits.w, nullptr, m->logits.s1, m->logits.cf,
+                                g->logits, c.n_vocab, rows, c.n_vocab, d));
     }
   }
   if (s.nospeech_rowmul > 0) {
-    ProfScope ps(m, PF_DEC_MISC, 0, 0);
+    ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
     fwd::launch_nospeech(st, g->logits, c.n_vocab, s.nospeech_rowmul, c.tok_no_speech, g->no_speech, s.B);
   }
   if (s.beam_tail) {
-    ProfScope ps(m, PF_DEC_SAMPLE, 0, 8.0 * rows * c.n_vocab);
+    ProfScope ps(m, PF_DEC_SAMPLE, 0, 8.0 * rows * c.n_vocab, st);
     fwd::launch_logits_process(st, gp, g->logits, g->sup_mask, g->hist2, g->cum2, g->d_step, g->done, g->cand_val,
                                g->cand_tok);
     fwd::launch_beam_update(st, gp, g->cand_val, g->cand_tok, g->hist2, g->cum2, g->kvidx2, g->cur_tok, g->d_step,
@@ -325,66 +357,69 @@ static int check_launch(const char* what) {
   return FW_OK;
 }
 
-}  // namespace fw
+// ---- one fw_generate call ------------------------------------------------------------------------------------
+struct GenRequest {
+  const Tensor* enc;
+  const int32_t* prompts;
+  const int32_t* prompt_offsets;
+  int B, P;
+  const fw_gen_opts* o;
+  int32_t* out_ids; int32_t* out_lens; float* out_scores; float* out_no_speech;
+  bool sampling;
+  int with_ts = 1, sot_pos = -1;   // from the prompt: no <|notimestamps|> -> timestamp rules; position of <sot>
+  int rc = FW_OK;
+  std::string err;
+  bool done = false;
+};
 
-using namespace fw;
+// calls that may share a decode run: same scalar options, same prompt length, same suppress list (beam / greedy
+// only: the hypotheses of a sampling call are rows of their own and run alone)
+static bool mergeable(const GenRequest& a, const GenRequest& b) {
+  if (a.sampling || b.sampling) return false;
+  const fw_gen_opts &x = *a.o, &y = *b.o;
+  if (a.P != b.P || x.beam_size != y.beam_size || x.patience != y.patience || x.num_hypotheses != y.num_hypotheses ||
+      x.length_penalty != y.length_penalty || x.repetition_penalty != y.repetition_penalty ||
+      x.no_repeat_ngram_size != y.no_repeat_ngram_size || x.max_length != y.max_length ||
+      x.max_initial_timestamp_index != y.max_initial_timestamp_index || x.suppress_blank != y.suppress_blank ||
+      x.min_new_tokens != y.min_new_tokens || x.n_suppress_tokens != y.n_suppress_tokens)
+    return false;
+  if (x.n_suppress_tokens && memcmp(x.suppress_tokens, y.suppress_tokens, x.n_suppress_tokens * sizeof(int32_t)))
+    return false;
+  // the timestamp rules are switched by <|notimestamps|> in the prompt, the <sot> position selects the no-speech
+  // row: both must agree; the prompts themselves may differ (language token per chunk, transcribe.py:212-220)
+  return a.with_ts == b.with_ts && a.sot_pos == b.sot_pos;
+}
 
-extern "C" {
-
-int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts, const int32_t* prompt_offsets,
-                    int32_t B, const fw_gen_opts* o, int32_t* out_ids, int32_t* out_lens, float* out_scores,
-                    float* out_no_speech) {
-  FW_CHECK_ARG(fm && enc_t && prompts && prompt_offsets && o && out_ids && out_lens && out_scores && out_no_speech,
-               "null argument");
-  Model* m = &fm->impl;
-  const Tensor* enc = &enc_t->impl;
+// Decode run over the concatenated chunks of `reqs` (all mergeable with reqs[0]).  Caller holds m->dec_mu.
+static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
+  int rc = gen_workspace_ensure(m);
+  if (rc) return rc;
   GenWorkspace* g = m->gen;
   const fw_config& c = m->cfg;
-  FW_CHECK_ARG(enc->owner == m, "encoder output belongs to a different model replica");
-  FW_CHECK_ARG(B == enc->B, "batch %d does not match the encoder output batch %d", B, enc->B);
-  FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
-  const int K = o->beam_size;
-  FW_CHECK_ARG(K >= 1 && K <= m->max_beam, "beam_size %d not in [1, max_beam=%d]", K, m->max_beam);
-  // random sampling (the sequential path's temperature fallback, transcribe.py:1433-1439): beam_size 1,
-  // sampling_topk 0 (whole distribution), num_hypotheses = best_of independent samples per chunk
-  const bool sampling = (K == 1 && o->sampling_topk != 1);
-  if (sampling) {
-    FW_CHECK_ARG(o->sampling_topk == 0, "sampling_topk must be 1 (greedy) or 0 (sample the whole distribution)");
-    FW_CHECK_ARG(o->sampling_temperature > 0.f, "sampling_temperature must be positive");
-    FW_CHECK_ARG(o->num_hypotheses >= 1 && B * o->num_hypotheses <= g->R,
-                 "batch x num_hypotheses = %d exceeds the %d decoder rows of this model", B * o->num_hypotheses, g->R);
-  } else {
-    FW_CHECK_ARG(o->num_hypotheses >= 1 && o->num_hypotheses <= std::max(K, 1),
-                 "num_hypotheses %d must be in [1, beam_size]", o->num_hypotheses);
-  }
-  FW_CHECK_ARG(o->patience > 0.f, "patience must be positive");
-  FW_CHECK_ARG(o->max_length >= 1, "max_length must be positive");
-  const int P = prompt_offsets[1] - prompt_offsets[0];
-  FW_CHECK_ARG(P >= 1, "prompts must not be empty");
-  for (int b = 0; b < B; ++b)
-    FW_CHECK_ARG(prompt_offsets[b + 1] - prompt_offsets[b] == P,
-                 "all prompts of a generate() call must have the same length (prompt %d has %d tokens, expected %d)",
-                 b, prompt_offsets[b + 1] - prompt_offsets[b], P);
-  FW_CHECK_ARG(P <= c.n_text_ctx, "prompt length %d exceeds the text context %d", P, c.n_text_ctx);
-  for (int i = 0; i < B * P; ++i)
-    FW_CHECK_ARG(prompts[i] >= 0 && prompts[i] < c.n_vocab, "prompt token %d out of range", prompts[i]);
-  int budget = max_new_tokens(std::min(o->max_length, c.n_text_ctx), P);
-  const int nh = o->num_hypotheses;
-  const int ml = o->max_length;
-  for (int i = 0; i < B * nh; ++i) { out_lens[i] = 0; out_scores[i] = 0.f; }
-  for (int b = 0; b < B; ++b) out_no_speech[b] = 0.f;
-
-  std::lock_guard<std::mutex> lk(m->mu);
-  FW_HIP(hipSetDevice(m->device));
-  hipStream_t st = m->stream;
-  int rc;
-  if ((rc = ensure_cross_kv(m, enc))) return rc;
-
+  const GenRequest& r0 = *reqs[0];
+  const fw_gen_opts* o = r0.o;
+  const int K = o->beam_size, P = r0.P;
+  const bool sampling = r0.sampling;
+  const int nh = o->num_hypotheses, ml = o->max_length;
   const int kv_div = sampling ? nh : 1;   // decode chunks per encoder chunk
+  int B = 0;
+  for (const GenRequest* r : reqs) B += r->B;
   const int Bx = B * kv_div;
+  FW_CHECK_ARG(Bx * K <= g->R && Bx <= g->R && B <= g->B, "decode run of %d chunks x %d rows exceeds the workspace", B,
+               kv_div * K);
+  const int budget = max_new_tokens(std::min(o->max_length, c.n_text_ctx), P);
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->dec_stream;
+  {
+    int b0 = 0;
+    for (const GenRequest* r : reqs) {
+      if ((rc = ensure_cross_kv(m, r->enc, b0))) return rc;
+      b0 += r->B;
+    }
+  }
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
-  gp.B = Bx; gp.K = K; gp.R = Bx * K; gp.P = P; gp.budget = budget;
+  gp.B = Bx; gp.K = K; gp.R = Bx * K; gp.P = P; gp.budget = budget; gp.kv_div = kv_div;
   gp.sample = sampling ? 1 : 0;
   gp.inv_temp = sampling ? 1.0f / o->sampling_temperature : 1.0f;
   gp.seed_lo = (unsigned)(o->seed & 0xffffffffu);
@@ -392,13 +427,8 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   gp.max_fin = std::max(1, (int)lroundf((float)K * o->patience));
   if (gp.max_fin > FIN_CAP - K) gp.max_fin = FIN_CAP - K;
   gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
-  bool has_no_ts = false;
-  int sot_pos = -1;
-  for (int i = 0; i < P; ++i) {
-    if (prompts[i] == c.tok_no_timestamps) has_no_ts = true;
-    if (prompts[i] == c.tok_sot) sot_pos = i;
-  }
-  gp.with_ts = has_no_ts ? 0 : 1;
+  const int sot_pos = r0.sot_pos;
+  gp.with_ts = r0.with_ts;
   gp.suppress_blank = o->suppress_blank ? 1 : 0;
   gp.min_new = o->min_new_tokens;
   gp.mits = o->max_initial_timestamp_index;
@@ -408,42 +438,47 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   gp.eot = c.tok_eot; gp.no_ts = c.tok_no_timestamps; gp.ts_begin = c.tok_timestamp_begin;
   gp.n_sup_begin = c.n_suppress_begin;
   for (int i = 0; i < c.n_suppress_begin; ++i) gp.sup_begin[i] = c.suppress_begin[i];
+  bool want_nsp = false;
+  for (const GenRequest* r : reqs) want_nsp = want_nsp || r->o->return_no_speech_prob;
 
-  // ---- state init ----
-  const size_t R = (size_t)g->R, NT = g->NT;
-  FW_HIP(hipMemsetAsync(g->hist2, 0, 2 * R * NT * sizeof(int), st));
-  FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * R * NT, st));
-  FW_HIP(hipMemsetAsync(g->cum2, 0, 2 * R * sizeof(float), st));
-  FW_HIP(hipMemsetAsync(g->done, 0, R * sizeof(int), st));
+  // ---- state init (only the rows of this run) ----
+  // (the ping-pong halves of hist2 / kvidx2 / cum2 are gp.R rows apart: the kernels index them with the run's R)
+  const size_t NT = g->NT, Rr = (size_t)gp.R;
+  FW_HIP(hipMemsetAsync(g->hist2, 0, 2 * Rr * NT * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * Rr * NT, st));
+  FW_HIP(hipMemsetAsync(g->cum2, 0, 2 * Rr * sizeof(float), st));
+  FW_HIP(hipMemsetAsync(g->done, 0, Rr * sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->n_done, 0, sizeof(int), st));
-  FW_HIP(hipMemsetAsync(g->n_fin, 0, R * sizeof(int), st));
+  FW_HIP(hipMemsetAsync(g->n_fin, 0, Rr * sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
-  FW_HIP(hipMemsetAsync(g->no_speech, 0, R * sizeof(float), st));
-  {
-    std::vector<uint8_t> mask(c.n_vocab, 0);
-    for (int i = 0; i < o->n_suppress_tokens; ++i) {
-      const int t = o->suppress_tokens[i];
-      if (t >= 0 && t < c.n_vocab) mask[t] = 1;
-    }
-    FW_HIP(hipMemcpyAsync(g->sup_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
-    FW_HIP(hipStreamSynchronize(st));  // mask is a stack-local buffer
+  FW_HIP(hipMemsetAsync(g->no_speech, 0, Rr * sizeof(float), st));
+  std::vector<uint8_t> mask(c.n_vocab, 0);
+  for (int i = 0; i < o->n_suppress_tokens; ++i) {
+    const int t = o->suppress_tokens[i];
+    if (t >= 0 && t < c.n_vocab) mask[t] = 1;
   }
-  // prompt tokens transposed to [pos][b]; first-step tokens replicated per beam
+  FW_HIP(hipMemcpyAsync(g->sup_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
+  // prompt tokens transposed to [pos][bx]; first-step tokens replicated per beam
   std::vector<int> ptok((size_t)P * Bx), first((size_t)Bx * K);
-  for (int bx = 0; bx < Bx; ++bx)
-    for (int p = 0; p < P; ++p) ptok[(size_t)p * Bx + bx] = prompts[prompt_offsets[bx / kv_div] + p];
-  for (int bx = 0; bx < Bx; ++bx)
-    for (int k = 0; k < K; ++k) first[(size_t)bx * K + k] = prompts[prompt_offsets[bx / kv_div] + P - 1];
+  {
+    int bx = 0;
+    for (const GenRequest* r : reqs)
+      for (int b = 0; b < r->B; ++b)
+        for (int j = 0; j < kv_div; ++j, ++bx) {
+          const int32_t* pr = r->prompts + r->prompt_offsets[b];
+          for (int p = 0; p < P; ++p) ptok[(size_t)p * Bx + bx] = pr[p];
+          for (int k = 0; k < K; ++k) first[(size_t)bx * K + k] = pr[P - 1];
+        }
+  }
   FW_HIP(hipMemcpyAsync(g->prompt_dev, ptok.data(), ptok.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FW_HIP(hipMemcpyAsync(g->cur_tok, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  FW_HIP(hipStreamSynchronize(st));
+  FW_HIP(hipStreamSynchronize(st));   // the host buffers above are locals
 
-  // ---- prompt forward (all but the last token): B rows, beam slot 0 of every chunk ----
+  // ---- prompt forward (all but the last token): Bx rows, beam slot 0 of every chunk ----
   for (int pos = 0; pos < P - 1; ++pos) {
     StepCfg s;
     s.rows = Bx; s.kmul = 1; s.B = Bx; s.pos_fixed = pos; s.P = P; s.tok = g->prompt_dev + (size_t)pos * Bx;
-    s.kv_div = kv_div;
-    s.need_logits = (pos == sot_pos) && o->return_no_speech_prob;
+    s.need_logits = (pos == sot_pos) && want_nsp;
     s.nospeech_rowmul = s.need_logits ? 1 : 0;
     s.beam_tail = false;
     s.done = g->done;
@@ -453,43 +488,51 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
 
   int steps_done = 0;
   if (budget > 0) {
-    // ---- step 0 (eager): last prompt token on all R rows; beams are identical copies ----
+    // ---- step 0 (eager): last prompt token on all rows; beams are identical copies ----
     StepCfg s;
     s.rows = Bx * K; s.kmul = K; s.B = Bx; s.pos_fixed = -1; s.P = P; s.tok = g->cur_tok;
-    s.kv_div = kv_div;
     s.need_logits = true;
-    s.nospeech_rowmul = (sot_pos == P - 1 && o->return_no_speech_prob) ? K : 0;
+    s.nospeech_rowmul = (sot_pos == P - 1 && want_nsp) ? K : 0;
     s.beam_tail = true;
     s.done = g->done;
     if ((rc = run_step(m, gp, s))) return rc;
     steps_done = 1;
     s.nospeech_rowmul = 0;
 
-    // ---- steps 1.. : one hipGraph replay per step ----
-    bool use_graph = g->graphs_enabled && !m->prof_on;
-    if (use_graph && !(g->graph_valid && memcmp(&g->graph_key, &gp, sizeof(gp)) == 0)) {
-      if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
-      g->graph_valid = false;
-      hipGraph_t graph = nullptr;
-      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        int rc2 = run_step(m, gp, s);
-        hipError_t e2 = hipStreamEndCapture(st, &graph);
-        if (rc2 == FW_OK && e2 == hipSuccess && graph &&
-            hipGraphInstantiate(&g->graph, graph, nullptr, nullptr, 0) == hipSuccess) {
-          g->graph_valid = true;
-          g->graph_key = gp;
+    // ---- steps 1.. : one hipGraph replay per step; graphs are cached per GenDev (everything the captured
+    //      kernels take by value, kv_div included) ----
+    hipGraphExec_t exec = nullptr;
+    if (g->graphs_enabled && !m->prof_on) {
+      for (GraphSlot& gs : g->graphs)
+        if (gs.exec && memcmp(&gs.key, &gp, sizeof(gp)) == 0) { exec = gs.exec; gs.stamp = ++g->graph_clock; }
+      if (!exec) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int rc2 = run_step(m, gp, s);
+          const hipError_t e2 = hipStreamEndCapture(st, &graph);
+          hipGraphExec_t ne = nullptr;
+          if (rc2 == FW_OK && e2 == hipSuccess && graph && hipGraphInstantiate(&ne, graph, nullptr, nullptr, 0) == hipSuccess) {
+            GraphSlot* slot = nullptr;
+            if (g->graphs.size() < 12) { g->graphs.emplace_back(); slot = &g->graphs.back(); }
+            else {   // evict the least recently used
+              slot = &g->graphs[0];
+              for (GraphSlot& gs : g->graphs) if (gs.stamp < slot->stamp) slot = &gs;
+              if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+            }
+            slot->exec = ne; slot->key = gp; slot->stamp = ++g->graph_clock;
+            exec = ne;
+          }
+          if (graph) (void)hipGraphDestroy(graph);
         }
-        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
       }
-      (void)hipGetLastError();
-      if (!g->graph_valid) use_graph = false;
     }
     int n_done_host = 0;
     while (steps_done < budget) {
       const int burst = std::min(4, budget - steps_done);
       for (int i = 0; i < burst; ++i) {
-        if (use_graph) {
-          hipError_t he = hipGraphLaunch(g->graph, st);
+        if (exec) {
+          hipError_t he = hipGraphLaunch(exec, st);
           if (he != hipSuccess) {
             set_error("hipGraphLaunch failed: %s", hipGetErrorString(he));
             return FW_ERUNTIME;
@@ -517,46 +560,178 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   FW_HIP(hipMemcpy(fin_score.data(), g->fin_score, fin_score.size() * sizeof(float), hipMemcpyDeviceToHost));
   FW_HIP(hipMemcpy(fin_tok.data(), g->fin_tok, fin_tok.size() * sizeof(int), hipMemcpyDeviceToHost));
   FW_HIP(hipMemcpy(nsp.data(), g->no_speech, Bx * sizeof(float), hipMemcpyDeviceToHost));
-  for (int b = 0; b < B; ++b) {
-    if (o->return_no_speech_prob) out_no_speech[b] = nsp[(size_t)b * kv_div];
-    // candidate hypotheses of encoder chunk b: (decode chunk, finished index)
-    std::vector<std::pair<int, int>> hyps;
-    for (int j = 0; j < kv_div; ++j) {
-      const int bx = b * kv_div + j;
-      for (int f = 0; f < n_fin[bx]; ++f) hyps.push_back({bx, f});
+  int cb = 0;   // first chunk of the request inside the run
+  for (GenRequest* r : reqs) {
+    for (int b = 0; b < r->B; ++b) {
+      const int gb = cb + b;
+      if (r->o->return_no_speech_prob) r->out_no_speech[b] = nsp[(size_t)gb * kv_div];
+      // candidate hypotheses of encoder chunk gb: (decode chunk, finished index)
+      std::vector<std::pair<int, int>> hyps;
+      for (int j = 0; j < kv_div; ++j) {
+        const int bx = gb * kv_div + j;
+        for (int f = 0; f < n_fin[bx]; ++f) hyps.push_back({bx, f});
+      }
+      std::stable_sort(hyps.begin(), hyps.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& bb) {
+        return fin_score[(size_t)a.first * FIN_CAP + a.second] > fin_score[(size_t)bb.first * FIN_CAP + bb.second];
+      });
+      for (int h = 0; h < nh && h < (int)hyps.size(); ++h) {
+        const size_t f = (size_t)hyps[h].first * FIN_CAP + hyps[h].second;
+        int len = fin_len[f];
+        if (len > ml) len = ml;
+        r->out_lens[b * nh + h] = len;
+        if (r->o->return_scores) r->out_scores[b * nh + h] = fin_score[f];
+        memcpy(r->out_ids + ((size_t)b * nh + h) * ml, &fin_tok[f * NT], (size_t)len * sizeof(int));
+      }
     }
-    std::stable_sort(hyps.begin(), hyps.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& bb) {
-      return fin_score[(size_t)a.first * FIN_CAP + a.second] > fin_score[(size_t)bb.first * FIN_CAP + bb.second];
-    });
-    for (int h = 0; h < nh && h < (int)hyps.size(); ++h) {
-      const size_t f = (size_t)hyps[h].first * FIN_CAP + hyps[h].second;
-      int len = fin_len[f];
-      if (len > ml) len = ml;
-      out_lens[b * nh + h] = len;
-      if (o->return_scores) out_scores[b * nh + h] = fin_score[f];
-      memcpy(out_ids + ((size_t)b * nh + h) * ml, &fin_tok[f * NT], (size_t)len * sizeof(int));
-    }
+    cb += r->B;
   }
   return FW_OK;
+}
+
+}  // namespace fw
+
+using namespace fw;
+
+extern "C" {
+
+int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts, const int32_t* prompt_offsets,
+                    int32_t B, const fw_gen_opts* o, int32_t* out_ids, int32_t* out_lens, float* out_scores,
+                    float* out_no_speech) {
+  FW_CHECK_ARG(fm && enc_t && prompts && prompt_offsets && o && out_ids && out_lens && out_scores && out_no_speech,
+               "null argument");
+  Model* m = &fm->impl;
+  Model* dm = decoder_of(m);
+  const Tensor* enc = &enc_t->impl;
+  const fw_config& c = m->cfg;
+  FW_CHECK_ARG(enc->owner && decoder_of(enc->owner) == dm, "encoder output belongs to a different model");
+  FW_CHECK_ARG(B == enc->B, "batch %d does not match the encoder output batch %d", B, enc->B);
+  FW_CHECK_ARG(B >= 1 && B <= dm->max_batch, "batch %d exceeds max_batch %d", B, dm->max_batch);
+  const int K = o->beam_size;
+  FW_CHECK_ARG(K >= 1 && K <= dm->max_beam, "beam_size %d not in [1, max_beam=%d]", K, dm->max_beam);
+  // random sampling (the sequential path's temperature fallback, transcribe.py:1433-1439): beam_size 1,
+  // sampling_topk 0 (whole distribution), num_hypotheses = best_of independent samples per chunk
+  const bool sampling = (K == 1 && o->sampling_topk != 1);
+  const int row_cap = std::max(dm->decode_batch, dm->max_batch) * dm->max_beam;
+  if (sampling) {
+    FW_CHECK_ARG(o->sampling_topk == 0, "sampling_topk must be 1 (greedy) or 0 (sample the whole distribution)");
+    FW_CHECK_ARG(o->sampling_temperature > 0.f, "sampling_temperature must be positive");
+    FW_CHECK_ARG(o->num_hypotheses >= 1 && B * o->num_hypotheses <= row_cap,
+                 "batch x num_hypotheses = %d exceeds the %d decoder rows of this model", B * o->num_hypotheses,
+                 row_cap);
+  } else {
+    FW_CHECK_ARG(o->num_hypotheses >= 1 && o->num_hypotheses <= std::max(K, 1),
+                 "num_hypotheses %d must be in [1, beam_size]", o->num_hypotheses);
+  }
+  FW_CHECK_ARG(o->patience > 0.f, "patience must be positive");
+  FW_CHECK_ARG(o->max_length >= 1, "max_length must be positive");
+  const int P = prompt_offsets[1] - prompt_offsets[0];
+  FW_CHECK_ARG(P >= 1, "prompts must not be empty");
+  for (int b = 0; b < B; ++b)
+    FW_CHECK_ARG(prompt_offsets[b + 1] - prompt_offsets[b] == P,
+                 "all prompts of a generate() call must have the same length (prompt %d has %d tokens, expected %d)",
+                 b, prompt_offsets[b + 1] - prompt_offsets[b], P);
+  FW_CHECK_ARG(P <= c.n_text_ctx, "prompt length %d exceeds the text context %d", P, c.n_text_ctx);
+  for (int i = 0; i < B * P; ++i)
+    FW_CHECK_ARG(prompts[prompt_offsets[0] + i] >= 0 && prompts[prompt_offsets[0] + i] < c.n_vocab,
+                 "prompt token %d out of range", prompts[prompt_offsets[0] + i]);
+  const int nh = o->num_hypotheses;
+  for (int i = 0; i < B * nh; ++i) { out_lens[i] = 0; out_scores[i] = 0.f; }
+  for (int b = 0; b < B; ++b) out_no_speech[b] = 0.f;
+
+  GenRequest req;
+  req.enc = enc; req.prompts = prompts; req.prompt_offsets = prompt_offsets; req.B = B; req.P = P; req.o = o;
+  req.out_ids = out_ids; req.out_lens = out_lens; req.out_scores = out_scores; req.out_no_speech = out_no_speech;
+  req.sampling = sampling;
+  for (int b = 0; b < B; ++b) {
+    // every prompt of the call must agree on what switches the decoding rules (true for every call site of the
+    // reference: one prompt per batch, language token swapped in place)
+    int wt = 1, sp = -1;
+    for (int i = 0; i < P; ++i) {
+      const int t = prompts[prompt_offsets[b] + i];
+      if (t == c.tok_no_timestamps) wt = 0;
+      if (t == c.tok_sot) sp = i;
+    }
+    if (b == 0) { req.with_ts = wt; req.sot_pos = sp; }
+    FW_CHECK_ARG(wt == req.with_ts && sp == req.sot_pos,
+                 "the prompts of a generate() call must agree on <|notimestamps|> and on the <|startoftranscript|> position");
+  }
+
+  DecodeGroup& grp = dm->grp;
+  std::unique_lock<std::mutex> lk(grp.mu);
+  grp.queue.push_back(&req);
+  while (!req.done) {
+    if (grp.leader_active) {
+      grp.cv.wait(lk);
+      continue;
+    }
+    // lead the next run: wait a moment for the requests of workers that are still encoding (they arrive within
+    // one encoder pass) unless half of the workspace is already claimed, then take every queued request that can
+    // share a run with the oldest one
+    grp.leader_active = true;
+    const int cap = std::max(dm->decode_batch, dm->max_batch);
+    if (cap > dm->max_batch && !grp.queue.front()->sampling) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        int queued = 0;
+        for (const GenRequest* r : grp.queue) queued += r->B;
+        if (queued * 2 >= cap || grp.encoding.load() <= 0) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(150)) break;
+        grp.cv.wait_for(lk, std::chrono::microseconds(200));
+      }
+    }
+    std::vector<GenRequest*> batch;
+    GenRequest* first = grp.queue.front();
+    int chunks = 0;
+    for (auto it = grp.queue.begin(); it != grp.queue.end();) {
+      GenRequest* r = *it;
+      if (r == first || (mergeable(*first, *r) && chunks + r->B <= cap)) {
+        batch.push_back(r);
+        chunks += r->B;
+        it = grp.queue.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    lk.unlock();
+    grp.n_runs.fetch_add(1);
+    grp.n_requests.fetch_add((int64_t)batch.size());
+    grp.n_chunks.fetch_add(chunks);
+    if (chunks > grp.max_run_chunks.load()) grp.max_run_chunks.store(chunks);
+    int rc;
+    {
+      std::lock_guard<std::mutex> dl(dm->dec_mu);
+      rc = generate_run(dm, batch);
+    }
+    const std::string err = rc ? fw_last_error() : "";
+    lk.lock();
+    for (GenRequest* r : batch) { r->rc = rc; r->err = err; r->done = true; }
+    grp.leader_active = false;
+    grp.cv.notify_all();
+  }
+  lk.unlock();
+  if (req.rc) set_error("%s", req.err.c_str());
+  return req.rc;
 }
 
 int32_t fw_detect_language(fw_model* fm, const fw_tensor* enc_t, int32_t B, int32_t* out_lang_ids,
                            float* out_probs) {
   FW_CHECK_ARG(fm && enc_t && out_lang_ids && out_probs, "null argument");
-  Model* m = &fm->impl;
+  Model* m = decoder_of(&fm->impl);
   const Tensor* enc = &enc_t->impl;
-  GenWorkspace* g = m->gen;
   const fw_config& c = m->cfg;
   FW_CHECK_ARG(c.is_multilingual && c.n_langs > 0, "detect_language needs a multilingual model");
-  FW_CHECK_ARG(enc->owner == m && B == enc->B && B <= m->max_batch, "bad encoder output / batch");
-  std::lock_guard<std::mutex> lk(m->mu);
+  FW_CHECK_ARG(enc->owner && decoder_of(enc->owner) == m && B == enc->B && B <= m->max_batch,
+               "bad encoder output / batch");
+  std::lock_guard<std::mutex> lk(m->dec_mu);
   FW_HIP(hipSetDevice(m->device));
-  hipStream_t st = m->stream;
   int rc;
-  if ((rc = ensure_cross_kv(m, enc))) return rc;
+  if ((rc = gen_workspace_ensure(m))) return rc;
+  GenWorkspace* g = m->gen;
+  hipStream_t st = m->dec_stream;
+  if ((rc = ensure_cross_kv(m, enc, 0))) return rc;
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
-  gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = 1; gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
+  gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = 1; gp.V = c.n_vocab; gp.n_text_ctx = g->NT; gp.kv_div = 1;
   std::vector<int> tok(B, c.tok_sot);
   FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * (size_t)g->R * g->NT, st));
   FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
@@ -691,11 +866,11 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
                             int32_t* out_n_pairs, float* out_probs) {
   FW_CHECK_ARG(fm && enc_t && start_seq && text_tokens && text_offsets && num_frames && out_pairs && out_n_pairs &&
                    out_probs, "null argument");
-  Model* m = &fm->impl;
+  Model* m = decoder_of(&fm->impl);
   const Tensor* enc = &enc_t->impl;
-  GenWorkspace* g = m->gen;
   const fw_config& c = m->cfg;
-  FW_CHECK_ARG(enc->owner == m && B == enc->B && B <= m->max_batch, "bad encoder output / batch");
+  FW_CHECK_ARG(enc->owner && decoder_of(enc->owner) == m && B == enc->B && B <= m->max_batch,
+               "bad encoder output / batch");
   FW_CHECK_ARG(n_start >= 1, "start_sequence must not be empty");
   FW_CHECK_ARG(median_filter_width >= 1 && median_filter_width <= 15 && (median_filter_width & 1),
                "median_filter_width must be odd and <= 15");
@@ -738,11 +913,13 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
   const int n_sel = (int)sel_heads.size();
   FW_CHECK_ARG(n_sel > 0, "no alignment heads");
 
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::lock_guard<std::mutex> lk(m->dec_mu);
   FW_HIP(hipSetDevice(m->device));
-  hipStream_t st = m->stream;
   int rc;
-  if ((rc = ensure_cross_kv(m, enc))) return rc;
+  if ((rc = gen_workspace_ensure(m))) return rc;
+  GenWorkspace* g = m->gen;
+  hipStream_t st = m->dec_stream;
+  if ((rc = ensure_cross_kv(m, enc, 0))) return rc;
 
   float *probs = nullptr, *stats = nullptr, *mat = nullptr, *tprob = nullptr;
   int *heads_dev = nullptr, *ntok_dev = nullptr, *nfr_dev = nullptr, *target_dev = nullptr;
@@ -790,7 +967,7 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
   }
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
-  gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = max_tok; gp.V = c.n_vocab; gp.n_text_ctx = g->NT;
+  gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = max_tok; gp.V = c.n_vocab; gp.n_text_ctx = g->NT; gp.kv_div = 1;
   for (int pos = 0; pos < max_tok; ++pos) {
     StepCfg s;
     s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = pos; s.P = max_tok; s.tok = g->prompt_dev + (size_t)pos * B;

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,8 +34,6 @@ void set_error(const char* fmt, ...);
 
 // ---- weight blob (what travels over RCCL at load time) --------------------------------
 #define FW_BLOB_MAGIC "FWAMDBL1"
-// default decoder GEMM form when FWAMD_DEC_GEMM is unset (0: LDS-staged, 1: fragment-major register streaming)
-#define FWAMD_DEC_FRAG_DEFAULT 1
 struct BlobHeader {
   char magic[8];
   int32_t version;
@@ -93,12 +94,25 @@ struct Tensor {  // fw_tensor
 };
 
 struct GenWorkspace;  // decoder-side buffers (decoder.hip)
+struct GenRequest;    // one fw_generate call waiting to be decoded (decoder.hip)
+
+// Decode group of a device: the worker replicas that share one decode workspace.  Concurrent fw_generate calls
+// with identical options are merged into ONE decode run (their rows share every weight byte streamed per step);
+// the first caller that finds no run in progress leads it, the others wait for their results.
+struct DecodeGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<GenRequest*> queue;
+  bool leader_active = false;
+  std::atomic<int> encoding{0};   // member encodes in flight: requests that are about to arrive
+  // statistics (fw_model_decode_stats): decode runs, fw_generate calls served, chunks decoded, largest run
+  std::atomic<int64_t> n_runs{0}, n_requests{0}, n_chunks{0};
+  std::atomic<int> max_run_chunks{0};
+};
 
 struct Model {
   fw_config cfg{};
   int compute_type = 0;
-  bool dec_frag = false;   // decoder linears + their inputs are stored MFMA-fragment-major (dec_gemm_frag_kernel)
-  bool dec_frag_i8 = false;   // same for the int8 decoder linears (dec_gemm_frag_i8_kernel), opt-in experiment
   int device = 0;
   int max_batch = 0, max_beam = 0;
   hipStream_t stream = nullptr;
@@ -143,7 +157,14 @@ struct Model {
   float* ws_xs = nullptr;                             //               its per-row scales [B*1500]
   int t_pad = 0;
 
+  // decode side.  A model either owns a decode workspace (gen, created on first use with room for decode_batch
+  // chunks, run on dec_stream under dec_mu) or has joined another model of the same device (decoder != null).
   GenWorkspace* gen = nullptr;
+  Model* decoder = nullptr;
+  int decode_batch = 0;
+  hipStream_t dec_stream = nullptr;
+  std::mutex dec_mu;
+  DecodeGroup grp;
 
   // pooled encoder-output buffers ([max_batch][T][d] each)
   std::mutex pool_mu;
@@ -159,8 +180,8 @@ struct Model {
 
 // profiling scope: brackets a group of launches with HIP events on the model's stream
 struct ProfScope {
-  Model* m; int fam; hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(Model* m_, int fam_, double flops, double bytes);
+  Model* m; int fam; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(Model* m_, int fam_, double flops, double bytes, hipStream_t st_ = nullptr);   // null: m->stream
   ~ProfScope();
 };
 void prof_collect(Model* m);
@@ -170,20 +191,25 @@ template <typename T>
 inline int dev_alloc_t(T** p, size_t n) { return dev_alloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
 
 // linear layer on "many rows": C = act(A W^T + b) + res   (encoder / prefill / align)
+// st == null: the model's encoder stream
 int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t a_bs, half_t* C, int64_t ldc,
                int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans,
-               int head_rows = 0);
+               int head_rows = 0, hipStream_t st = nullptr);
 
+// xq / xs == null: the encoder's quantisation workspace (m->ws_xq / m->ws_xs)
 int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, half_t* C, int64_t ldc, int64_t c_bs,
-                  const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans, int head_rows);
+                  const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans, int head_rows,
+                  hipStream_t st = nullptr, int8_t* xq = nullptr, float* xs = nullptr);
 
 // encoder forward on the channel-last mel image already in m->ws_mel_cl; result into out [B][1500][d]
 int run_encoder(Model* m, int B, half_t* out);
 
 // decoder entry points (decoder.hip)
 uint64_t next_tensor_id();
-int gen_workspace_create(Model* m);
+int gen_workspace_ensure(Model* dm);          // creates dm's decode workspace on first use (caller holds dm->dec_mu)
 void gen_workspace_free(Model* m);
+int64_t gen_workspace_bytes(const Model* m, int decode_batch);
+inline Model* decoder_of(Model* m) { return m->decoder ? m->decoder : m; }
 
 }  // namespace fw
 

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 
+#include "dec_kernels.h"
 #include "kernels.h"
 
 namespace fw {
@@ -52,18 +53,19 @@ static hipEvent_t ev_get(Model* m) {
   (void)hipEventCreate(&e);
   return e;
 }
-ProfScope::ProfScope(Model* m_, int fam_, double flops, double bytes) : m(m_), fam(fam_) {
+ProfScope::ProfScope(Model* m_, int fam_, double flops, double bytes, hipStream_t st_)
+    : m(m_), fam(fam_), st(st_ ? st_ : m_->stream) {
   if (!m->prof_on) return;
   a = ev_get(m);
   b = ev_get(m);
   m->prof[fam].flops += flops;
   m->prof[fam].bytes += bytes;
   m->prof[fam].launches += 1;
-  (void)hipEventRecord(a, m->stream);
+  (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
   if (!a) return;
-  (void)hipEventRecord(b, m->stream);
+  (void)hipEventRecord(b, st);
   m->pending.push_back({a, b, fam});
 }
 void prof_collect(Model* m) {
@@ -167,19 +169,20 @@ static int check_config(const fw_config* c) {
   FW_CHECK_ARG(c->n_vocab > c->tok_timestamp_begin && c->tok_timestamp_begin > 0, "bad vocabulary layout");
   FW_CHECK_ARG(c->n_align_heads >= 0 && c->n_align_heads <= FW_MAX_ALIGN_HEADS, "too many alignment heads");
   FW_CHECK_ARG(c->n_suppress_begin >= 0 && c->n_suppress_begin <= 8, "n_suppress_begin out of range");
+  // the logits-rules kernel keeps a row's logits in registers: 56 values x 1024 threads
+  FW_CHECK_ARG(c->n_vocab <= 57344, "n_vocab %d exceeds the 57344 ids the logits kernel holds per row", c->n_vocab);
+  const int toks[] = {c->tok_eot, c->tok_sot, c->tok_translate, c->tok_transcribe, c->tok_sot_lm, c->tok_sot_prev,
+                      c->tok_no_speech, c->tok_no_timestamps, c->tok_timestamp_begin};
+  for (int t : toks) FW_CHECK_ARG(t >= 0 && t < c->n_vocab, "special token id %d outside the vocabulary of %d", t, c->n_vocab);
+  FW_CHECK_ARG(c->n_langs >= 0 && c->tok_lang_begin >= 0 && c->tok_lang_begin + c->n_langs <= c->n_vocab,
+               "language ids [%d, %d) outside the vocabulary of %d", c->tok_lang_begin, c->tok_lang_begin + c->n_langs,
+               c->n_vocab);
+  for (int i = 0; i < c->n_suppress_begin; ++i)
+    FW_CHECK_ARG(c->suppress_begin[i] >= 0 && c->suppress_begin[i] < c->n_vocab, "suppress_begin id out of range");
   return FW_OK;
 }
 
-// Build the device blob image on the host. All tensors fp16, final kernel layouts.
-// decoder skinny-GEMM form, decided when the weights are packed (the blob carries the flag, so worker replicas
-// and other ranks that receive the blob agree): fragment-major register-streaming kernel unless FWAMD_DEC_GEMM=lds
-static bool dec_frag_enabled() {
-  const char* e = getenv("FWAMD_DEC_GEMM");
-  if (e && e[0] == 'l') return false;
-  if (e && e[0] == 'f') return true;
-  return FWAMD_DEC_FRAG_DEFAULT;
-}
-
+// Build the device blob image on the host: all tensors in their final kernel layouts.
 static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compute_type,
                      std::vector<uint8_t>& blob) {
   const int d = cfg->d_model, nm = cfg->n_mels;
@@ -349,69 +352,48 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   }
 #undef TRY
 
-  // Fragment-major decoder linears (dec_kernels.hip: dec_gemm_frag_kernel): W[n][k] moves to
-  // ((n/16 * K/32 + k/32) * 64 + 16*((k/8)%4) + n%16) * 8 + k%8, so that the 16 bytes lane l feeds to the MFMA
-  // for k-step ks of column tile nt sit at ((nt*KS + ks)*64 + l)*16 B.  fp16 mode only; the big "many rows"
-  // GEMM (cross.kv) and the logits projection keep [N][K].
-  const bool frag = dec_frag_enabled() && !i8;
-  if (frag) {
-    for (PackItem& it : items) {
-      const std::string& nm = it.name;
-      if (nm.compare(0, 4, "dec.") != 0 || it.ndim != 2 || it.dtype != 1) continue;
-      auto ends = [&](const char* suf) {
-        const size_t n = strlen(suf);
-        return nm.size() >= n && nm.compare(nm.size() - n, n, suf) == 0;
-      };
-      if (!(ends("self.qkv.wf") || ends("self.out.w") || ends("cross.q.wf") || ends("cross.out.w") ||
-            ends("ffn1.wf") || ends("ffn2.w")))
-        continue;
-      const int64_t N = it.dims[0], K = it.dims[1];
-      if (N % 16 || K % 32) {
-        set_error("fragment-major packing needs N %% 16 == 0 and K %% 32 == 0 (%s is %lld x %lld)", nm.c_str(),
-                  (long long)N, (long long)K);
-        return FW_EINVAL;
-      }
-      std::vector<uint16_t> src;
-      src.swap(it.data);
-      it.data.resize(src.size());
-      const int64_t KS = K / 32;
-      for (int64_t n = 0; n < N; ++n)
-        for (int64_t k = 0; k < K; ++k)
-          it.data[(((n >> 4) * KS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7)] = src[n * K + k];
+  // Fragment-major decoder linears (dec_kernels.hip): the 16 bytes lane l feeds to the MFMA for k-step ks of
+  // column tile nt sit at ((nt*KS + ks)*64 + l)*16 B, i.e. element W[n][k] moves to
+  //   fp16: ((n/16 * K/32 + k/32) * 64 + 16*((k/8)%4)  + n%16) * 8  + k%8     (32 elements per k-step)
+  //   int8: ((n/16 * K/64 + k/64) * 64 + 16*((k/16)%4) + n%16) * 16 + k%16    (64 elements per k-step)
+  // The six per-layer linears and the vocabulary projection are stored this way (the projection's N is padded
+  // to a whole tile with zero rows); the big "many rows" GEMM (cross.kv) keeps [N][K].
+  for (PackItem& it : items) {
+    const std::string& nm = it.name;
+    if (nm.compare(0, 4, "dec.") != 0 || it.ndim != 2 || it.dtype != (i8 ? 2 : 1)) continue;
+    auto ends = [&](const char* suf) {
+      const size_t n = strlen(suf);
+      return nm.size() >= n && nm.compare(nm.size() - n, n, suf) == 0;
+    };
+    const bool hit = i8 ? (ends("self.qkv.wq") || ends("self.out.wq") || ends("cross.q.wq") || ends("cross.out.wq") ||
+                           ends("ffn1.wq") || ends("ffn2.wq") || nm == "dec.logits.wq")
+                        : (ends("self.qkv.wf") || ends("self.out.w") || ends("cross.q.wf") || ends("cross.out.w") ||
+                           ends("ffn1.wf") || ends("ffn2.w") || nm == "dec.logits.wf");
+    if (!hit) continue;
+    const int64_t N = it.dims[0], K = it.dims[1], KE = i8 ? 64 : 32, OCT = KE / 4;
+    const bool logits = nm.compare(0, 10, "dec.logits") == 0;
+    if ((!logits && N % 32) || K % KE) {
+      set_error("fragment-major packing needs N %% 32 == 0 and K %% %lld == 0 (%s is %lld x %lld)", (long long)KE,
+                nm.c_str(), (long long)N, (long long)K);
+      return FW_EINVAL;
     }
-  }
-
-  // int8 fragment-major decoder linears (dec_gemm_frag_i8_kernel; experiment, opt-in at pack time with
-  // FWAMD_DEC_GEMM_I8=frag): Wq[n][k] moves to ((n/16 * K/64 + k/64) * 64 + 16*((k/16)%4) + n%16) * 16 + k%16
-  bool frag_i8 = false;
-  if (i8) {
-    const char* e8 = getenv("FWAMD_DEC_GEMM_I8");
-    frag_i8 = e8 && e8[0] == 'f';
-  }
-  if (frag_i8) {
-    for (PackItem& it : items) {
-      const std::string& nm = it.name;
-      if (nm.compare(0, 4, "dec.") != 0 || it.ndim != 2 || it.dtype != 2) continue;
-      auto ends = [&](const char* suf) {
-        const size_t n = strlen(suf);
-        return nm.size() >= n && nm.compare(nm.size() - n, n, suf) == 0;
-      };
-      if (!(ends("self.qkv.wq") || ends("self.out.wq") || ends("cross.q.wq") || ends("cross.out.wq") ||
-            ends("ffn1.wq") || ends("ffn2.wq")))
-        continue;
-      const int64_t N = it.dims[0], K = it.dims[1];
-      if (N % 16 || K % 64) {
-        set_error("int8 fragment-major packing needs N %% 16 == 0 and K %% 64 == 0 (%s is %lld x %lld)", nm.c_str(),
-                  (long long)N, (long long)K);
-        return FW_EINVAL;
-      }
+    const int64_t NP = (N + 15) / 16 * 16, KS = K / KE;
+    it.dims[0] = NP;   // the stored extent (padding rows are zero)
+    auto at = [&](int64_t n, int64_t k) {
+      return (((n >> 4) * KS + k / KE) * 64 + ((k / OCT) & 3) * 16 + (n & 15)) * OCT + (k % OCT);
+    };
+    if (i8) {
       std::vector<int8_t> src;
       src.swap(it.qdata);
-      it.qdata.resize(src.size());
-      const int64_t KS = K / 64;
+      it.qdata.assign((size_t)NP * K, 0);
       for (int64_t n = 0; n < N; ++n)
-        for (int64_t k = 0; k < K; ++k)
-          it.qdata[(((n >> 4) * KS + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (n & 15)) * 16 + (k & 15)] = src[n * K + k];
+        for (int64_t k = 0; k < K; ++k) it.qdata[at(n, k)] = src[n * K + k];
+    } else {
+      std::vector<uint16_t> src;
+      src.swap(it.data);
+      it.data.assign((size_t)NP * K, 0);
+      for (int64_t n = 0; n < N; ++n)
+        for (int64_t k = 0; k < K; ++k) it.data[at(n, k)] = src[n * K + k];
     }
   }
 
@@ -437,7 +419,7 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   h.n_tensors = (int32_t)items.size();
   h.total_bytes = off;
   h.compute_type = compute_type;
-  h.reserved = (frag ? 1 : 0) | (frag_i8 ? 2 : 0);   // bit 0 / 1: fp16 / int8 decoder linears are fragment-major
+  h.reserved = 4;   // layout generation: 4 = decoder linears and the vocabulary projection fragment-major
   h.cfg = *cfg;
   memcpy(blob.data(), &h, sizeof(h));
   memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
@@ -671,8 +653,11 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   Model* m = &fm->impl;
   m->cfg = h.cfg;
   m->compute_type = h.compute_type;
-  m->dec_frag = (h.reserved & 1) != 0;
-  m->dec_frag_i8 = (h.reserved & 2) != 0;
+  if (h.reserved != 4) {
+    delete fm;
+    set_error("weight blob was packed by an older libfwamd (layout generation %d, expected 4): repack it", h.reserved);
+    return FW_EINVAL;
+  }
   m->device = device;
   m->max_batch = max_batch;
   m->max_beam = max_beam;
@@ -696,7 +681,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   if ((rc = bind_weights(m))) return fail(rc);
   if ((rc = setup_logmel_consts(m))) return fail(rc);
   if ((rc = alloc_workspaces(m))) return fail(rc);
-  if ((rc = gen_workspace_create(m))) return fail(rc);
+  m->decode_batch = max_batch;   // the decode workspace itself is created on first use (decoder.hip)
   he = hipDeviceSynchronize();
   if (he != hipSuccess) {
     set_error("device sync after model setup failed: %s", hipGetErrorString(he));
@@ -713,7 +698,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
 // ---------------------------------------------------------------- layers
 int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t a_bs, half_t* C, int64_t ldc,
                int64_t c_bs, const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans,
-               int head_rows) {
+               int head_rows, hipStream_t st) {
   fwk::GemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = A; p.lda = lda; p.a_bstride = a_bs;
@@ -724,7 +709,7 @@ int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t
   p.M = M; p.N = L.N; p.K = L.K;
   p.act = act;
   p.head_rows = head_rows;
-  if (fwk::launch_gemm(m->stream, p, batch, trans) != 0) {
+  if (fwk::launch_gemm(st ? st : m->stream, p, batch, trans) != 0) {
     set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%lld", M, L.N, L.K, (long long)lda);
     return FW_ERUNTIME;
   }
@@ -736,13 +721,13 @@ int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t
 // rows quantised by the previous call (fused Q|K and V projections share their input).
 int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, half_t* C, int64_t ldc, int64_t c_bs,
                   const half_t* res, int64_t ldr, int64_t r_bs, int M, int batch, int act, bool trans,
-                  int head_rows) {
-  if (A)
-    fwk::launch_quant_rows(m->stream, A, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, m->ws_xq, m->ws_xs, batch * M,
-                           L.K);
+                  int head_rows, hipStream_t st, int8_t* xq, float* xs) {
+  if (!st) st = m->stream;
+  if (!xq) { xq = m->ws_xq; xs = m->ws_xs; }
+  if (A) fwk::launch_quant_rows(st, A, L.K, ln ? ln->g : nullptr, ln ? ln->b : nullptr, xq, xs, batch * M, L.K);
   fwk::GemmParams p;
   memset(&p, 0, sizeof(p));
-  p.A = reinterpret_cast<const half_t*>(m->ws_xq); p.lda = L.K; p.a_bstride = (int64_t)M * L.K;
+  p.A = reinterpret_cast<const half_t*>(xq); p.lda = L.K; p.a_bstride = (int64_t)M * L.K;
   p.W = reinterpret_cast<const half_t*>(L.wq); p.ldw = L.K;
   p.bias = L.b;
   p.res = res; p.ldr = ldr; p.r_bstride = r_bs;
@@ -750,8 +735,8 @@ int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, ha
   p.M = M; p.N = L.N; p.K = L.K;
   p.act = act;
   p.head_rows = head_rows;
-  p.a_scale = m->ws_xs; p.as_bstride = M; p.w_scale = L.wscale;
-  if (fwk::launch_gemm(m->stream, p, batch, trans) != 0) {
+  p.a_scale = xs; p.as_bstride = M; p.w_scale = L.wscale;
+  if (fwk::launch_gemm(st, p, batch, trans) != 0) {
     set_error("int8 gemm: unsupported shape M=%d N=%d K=%d", M, L.N, L.K);
     return FW_ERUNTIME;
   }
@@ -1040,7 +1025,9 @@ void fw_model_free(fw_model* fm) {
   }
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->dec_stream) (void)hipStreamSynchronize(m->dec_stream);
   gen_workspace_free(m);
+  if (m->dec_stream) (void)hipStreamDestroy(m->dec_stream);
   for (half_t* p : m->enc_pool) (void)hipFree(p);
   m->enc_pool.clear();
   void* ptrs[] = {m->lm_consts, m->lm_filtT, m->ws_pcm, m->ws_offsets, m->ws_raw, m->ws_chunk_max, m->ws_nframes,
@@ -1071,6 +1058,60 @@ int32_t fw_model_info(const fw_model* fm, fw_config* cfg_out, int32_t* compute_t
   if (device_index) *device_index = m->device;
   if (max_batch) *max_batch = m->max_batch;
   if (max_beam) *max_beam = m->max_beam;
+  return FW_OK;
+}
+
+int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
+  FW_CHECK_ARG(fm, "null model");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(!m->decoder, "this model has joined another model's decoder");
+  FW_CHECK_ARG(decode_batch >= 1, "decode_batch must be positive");
+  std::lock_guard<std::mutex> lk(m->dec_mu);
+  FW_HIP(hipSetDevice(m->device));
+  // whole encoder batches, at least one, at most what fits in 70 % of the free HBM (and 2048 rows)
+  int want = std::max(decode_batch, m->max_batch) / m->max_batch * m->max_batch;
+  size_t free_b = 0, total_b = 0;
+  FW_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (m->gen) free_b += (size_t)gen_workspace_bytes(m, m->decode_batch);
+  while (want > m->max_batch &&
+         (gen_workspace_bytes(m, want) > (int64_t)(0.7 * (double)free_b) || (int64_t)want * m->max_beam > 2048))
+    want -= m->max_batch;
+  if (m->gen && want == m->decode_batch) return FW_OK;
+  if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
+  gen_workspace_free(m);
+  m->decode_batch = want;
+  return gen_workspace_ensure(m);
+}
+
+int32_t fw_model_decode_batch(const fw_model* fm) {
+  if (!fm) return 0;
+  const Model* m = fm->impl.decoder ? fm->impl.decoder : &fm->impl;
+  return std::max(m->decode_batch, m->max_batch);
+}
+
+int32_t fw_model_decode_stats(const fw_model* fm, int64_t* runs, int64_t* requests, int64_t* chunks,
+                              int32_t* max_run_chunks) {
+  FW_CHECK_ARG(fm, "null model");
+  const Model* m = fm->impl.decoder ? fm->impl.decoder : &fm->impl;
+  if (runs) *runs = m->grp.n_runs.load();
+  if (requests) *requests = m->grp.n_requests.load();
+  if (chunks) *chunks = m->grp.n_chunks.load();
+  if (max_run_chunks) *max_run_chunks = m->grp.max_run_chunks.load();
+  return FW_OK;
+}
+
+int32_t fw_model_join_decoder(fw_model* fm, fw_model* decoder) {
+  FW_CHECK_ARG(fm && decoder && fm != decoder, "need two distinct models");
+  Model* m = &fm->impl;
+  Model* d = &decoder->impl;
+  FW_CHECK_ARG(!d->decoder, "the decoder model has itself joined another decoder");
+  FW_CHECK_ARG(m->device == d->device && m->blob == d->blob && m->max_batch == d->max_batch && m->max_beam == d->max_beam,
+               "models that share a decoder must share device, weight blob, max_batch and max_beam");
+  std::lock_guard<std::mutex> lk(m->dec_mu);
+  FW_HIP(hipSetDevice(m->device));
+  if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
+  gen_workspace_free(m);
+  m->decoder = d;
   return FW_OK;
 }
 
@@ -1132,10 +1173,24 @@ int32_t fw_logmel_full(fw_model* fm, const float* pcm, int64_t n_samples, float*
   return FW_OK;
 }
 
+namespace {
+// tells the device's decode group that a request is on its way (the leader of the next decode run waits a moment
+// for it instead of starting with a nearly empty workspace)
+struct EncodingMark {
+  fw::DecodeGroup& g;
+  explicit EncodingMark(fw::Model* m) : g(fw::decoder_of(m)->grp) { g.encoding.fetch_add(1); }
+  ~EncodingMark() {
+    g.encoding.fetch_sub(1);
+    g.cv.notify_all();
+  }
+};
+}  // namespace
+
 int32_t fw_encode(fw_model* fm, const float* features, int32_t B, fw_tensor** out) {
   FW_CHECK_ARG(fm && features && out, "null argument");
   Model* m = &fm->impl;
   FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  EncodingMark mark(m);
   std::lock_guard<std::mutex> lk(m->mu);
   FW_HIP(hipSetDevice(m->device));
   FW_HIP(hipMemcpyAsync(m->ws_feat32, features, (size_t)B * m->cfg.n_mels * 3000 * sizeof(float),
@@ -1183,6 +1238,7 @@ int32_t fw_encode_pcm(fw_model* fm, const float* pcm, const int64_t* offsets, in
   FW_CHECK_ARG(fm && offsets && out, "null argument");
   Model* m = &fm->impl;
   FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  EncodingMark mark(m);
   std::lock_guard<std::mutex> lk(m->mu);
   FW_HIP(hipSetDevice(m->device));
   int64_t total; int mf;
@@ -1198,6 +1254,7 @@ int32_t fw_encode_pcm_dev(fw_model* fm, const float* pcm_dev, const int64_t* off
   FW_CHECK_ARG(fm && pcm_dev && offsets && out, "null argument");
   Model* m = &fm->impl;
   FW_CHECK_ARG(B >= 1 && B <= m->max_batch, "batch %d exceeds max_batch %d", B, m->max_batch);
+  EncodingMark mark(m);
   std::lock_guard<std::mutex> lk(m->mu);
   FW_HIP(hipSetDevice(m->device));
   return encode_pcm_common(m, pcm_dev, offsets, B, out);
@@ -1295,6 +1352,7 @@ int32_t fw_synchronize(fw_model* fm) {
   FW_CHECK_ARG(fm, "null model");
   FW_HIP(hipSetDevice(fm->impl.device));
   FW_HIP(hipStreamSynchronize(fm->impl.stream));
+  if (fm->impl.dec_stream) FW_HIP(hipStreamSynchronize(fm->impl.dec_stream));
   return FW_OK;
 }
 int32_t fw_dev_alloc(fw_model* fm, int64_t bytes, void** out_dev) {
@@ -1390,6 +1448,179 @@ int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* 
   if (dWq) (void)hipFree(dWq);
   if (dWs) (void)hipFree(dWs);
   return rc;
+}
+
+// fragment-major position of element (row, k) of a [rows][K] operand: 16-row tiles x k-steps of KE elements, the
+// 16 bytes of lane l = 16*((k / (KE/4)) % 4) + row % 16 contiguous (dec_kernels.hip)
+static inline size_t frag_pos(int64_t row, int64_t k, int64_t K, int KE) {
+  const int OCT = KE / 4;
+  return (size_t)((((row >> 4) * (K / KE) + k / KE) * 64 + ((k / OCT) & 3) * 16 + (row & 15)) * OCT + (k % OCT));
+}
+
+int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const float* bias, const float* ln_g,
+                           const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
+                           int32_t use_int8, float* out, float* out_from_frag) {
+  FW_CHECK_ARG(fm && x && W && out && out_from_frag, "null argument");
+  FW_CHECK_ARG(R >= 1 && N % 32 == 0 && K % 64 == 0, "need R >= 1, N %% 32 == 0, K %% 64 == 0");
+  FW_CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr), "ln_g and ln_b go together");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  const int R16 = (R + 15) / 16 * 16;
+  auto h = [](float v) { return f16_bits_to_f32(f32_to_f16_bits(v)); };
+  std::vector<void*> owned;
+  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+    int rc = dev_alloc(dst, bytes);
+    if (rc) return rc;
+    owned.push_back(*dst);
+    FW_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return FW_OK;
+  };
+  auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+  int rc = FW_OK;
+  half_t *d_res = nullptr, *d_bias = nullptr, *d_out = nullptr, *d_of = nullptr;
+  std::vector<uint16_t> tmp;
+  if (res) {
+    tmp.resize((size_t)R * N);
+    for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = f32_to_f16_bits(res[i]);
+    if ((rc = up(tmp.data(), tmp.size() * 2, (void**)&d_res))) { cleanup(); return rc; }
+  }
+  if ((rc = dev_alloc_t(&d_out, (size_t)R * N))) { cleanup(); return rc; }
+  owned.push_back(d_out);
+  if ((rc = dev_alloc_t(&d_of, (size_t)R16 * N))) { cleanup(); return rc; }
+  owned.push_back(d_of);
+  FW_HIP(hipMemset(d_of, 0, (size_t)R16 * N * 2));
+  if (use_int8) {
+    if (m->compute_type != FW_COMPUTE_INT8_FLOAT16 || ln_g) {
+      cleanup();
+      set_error("int8 decoder-linear test needs an int8_float16 model and no LayerNorm");
+      return FW_EINVAL;
+    }
+    std::vector<int8_t> wq((size_t)N * K);
+    std::vector<float> ws(N);
+    for (int n = 0; n < N; ++n) {
+      float amax = 0.f;
+      for (int k = 0; k < K; ++k) amax = std::max(amax, fabsf(h(W[(size_t)n * K + k])));
+      const float sc = amax > 0.f ? 127.0f / amax : 0.f;
+      for (int k = 0; k < K; ++k) wq[frag_pos(n, k, K, 64)] = (int8_t)lrintf(h(W[(size_t)n * K + k]) * sc);
+      ws[n] = amax > 0.f ? amax / 127.0f : 1.0f;
+    }
+    int8_t *d_wq = nullptr, *d_xq = nullptr;
+    float *d_ws = nullptr, *d_xs = nullptr;
+    half_t* d_x = nullptr;
+    tmp.resize((size_t)R * K);
+    for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = f32_to_f16_bits(x[i]);
+    if ((rc = up(wq.data(), wq.size(), (void**)&d_wq)) || (rc = up(ws.data(), ws.size() * 4, (void**)&d_ws)) ||
+        (rc = up(tmp.data(), tmp.size() * 2, (void**)&d_x))) { cleanup(); return rc; }
+    if (bias) {
+      tmp.resize(N);
+      for (int n = 0; n < N; ++n) tmp[n] = f32_to_f16_bits(bias[n]);
+      if ((rc = up(tmp.data(), (size_t)N * 2, (void**)&d_bias))) { cleanup(); return rc; }
+    }
+    if ((rc = dev_alloc_t(&d_xq, (size_t)R16 * K))) { cleanup(); return rc; }
+    owned.push_back(d_xq);
+    if ((rc = dev_alloc_t(&d_xs, (size_t)R16))) { cleanup(); return rc; }
+    owned.push_back(d_xs);
+    FW_HIP(hipMemset(d_xq, 0, (size_t)R16 * K));
+    fwk::launch_quant_rows(st, d_x, K, nullptr, nullptr, d_xq, d_xs, R, K, 1);
+    if (fwd::launch_dec_gemm_frag_i8(st, d_xq, d_xs, d_wq, d_ws, d_bias, d_res, N, d_out, N, R, N, K, act) != 0) {
+      cleanup();
+      set_error("int8 decoder linear: unsupported shape R=%d N=%d K=%d", R, N, K);
+      return FW_ERUNTIME;
+    }
+    rc = download_f16(m, d_out, (size_t)R * N, out);
+    if (!rc) memcpy(out_from_frag, out, (size_t)R * N * sizeof(float));
+    cleanup();
+    return rc;
+  }
+  // fp16: fold the LayerNorm exactly like the weight packer (add_folded)
+  std::vector<uint16_t> wf((size_t)N * K), xf((size_t)R16 * K, 0);
+  std::vector<float> s1(N, 0.f), cf(N, 0.f);
+  for (int n = 0; n < N; ++n) {
+    double a1 = 0.0, ac = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const float wv = h(W[(size_t)n * K + k]);
+      const uint16_t wg = ln_g ? f32_to_f16_bits(wv * h(ln_g[k])) : f32_to_f16_bits(wv);
+      wf[frag_pos(n, k, K, 32)] = wg;
+      a1 += (double)f16_bits_to_f32(wg);
+      if (ln_g) ac += (double)wv * (double)h(ln_b[k]);
+    }
+    if (bias) ac += (double)h(bias[n]);
+    s1[n] = (float)a1;
+    cf[n] = (float)ac;
+  }
+  for (int r = 0; r < R; ++r)
+    for (int k = 0; k < K; ++k) xf[frag_pos(r, k, K, 32)] = f32_to_f16_bits(x[(size_t)r * K + k]);
+  half_t *d_wf = nullptr, *d_xf = nullptr;
+  float *d_s1 = nullptr, *d_cf = nullptr;
+  if ((rc = up(wf.data(), wf.size() * 2, (void**)&d_wf)) || (rc = up(xf.data(), xf.size() * 2, (void**)&d_xf))) {
+    cleanup();
+    return rc;
+  }
+  if (ln_g) {
+    if ((rc = up(s1.data(), (size_t)N * 4, (void**)&d_s1)) || (rc = up(cf.data(), (size_t)N * 4, (void**)&d_cf))) {
+      cleanup();
+      return rc;
+    }
+  } else if (bias) {
+    tmp.resize(N);
+    for (int n = 0; n < N; ++n) tmp[n] = f32_to_f16_bits(bias[n]);
+    if ((rc = up(tmp.data(), (size_t)N * 2, (void**)&d_bias))) { cleanup(); return rc; }
+  }
+  if (fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act) != 0) {
+    cleanup();
+    set_error("decoder linear: unsupported shape R=%d N=%d K=%d", R, N, K);
+    return FW_ERUNTIME;
+  }
+  rc = download_f16(m, d_out, (size_t)R * N, out);
+  std::vector<float> of((size_t)R16 * N);
+  if (!rc) rc = download_f16(m, d_of, (size_t)R16 * N, of.data());
+  if (!rc)
+    for (int r = 0; r < R; ++r)
+      for (int n = 0; n < N; ++n) out_from_frag[(size_t)r * N + n] = of[frag_pos(r, n, N, 32)];
+  cleanup();
+  return rc;
+}
+
+int32_t fw_test_dec_logits(fw_model* fm, const float* x, int32_t R, float* out) {
+  FW_CHECK_ARG(fm && x && out && R >= 1, "bad argument");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  const int d = m->cfg.d_model, V = m->cfg.n_vocab, R16 = (R + 15) / 16 * 16;
+  const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
+  std::vector<uint16_t> xh((size_t)R16 * d, 0);
+  for (int r = 0; r < R; ++r)
+    for (int k = 0; k < d; ++k)
+      xh[i8 ? (size_t)r * d + k : frag_pos(r, k, d, 32)] = f32_to_f16_bits(x[(size_t)r * d + k]);
+  half_t* d_x = nullptr;
+  int8_t* d_xq = nullptr;
+  float *d_xs = nullptr, *d_out = nullptr;
+  int rc;
+  auto cleanup = [&]() { for (void* p : {(void*)d_x, (void*)d_xq, (void*)d_xs, (void*)d_out}) if (p) (void)hipFree(p); };
+  if ((rc = dev_alloc_t(&d_x, xh.size())) || (rc = dev_alloc_t(&d_out, (size_t)R * V))) { cleanup(); return rc; }
+  FW_HIP(hipMemcpy(d_x, xh.data(), xh.size() * 2, hipMemcpyHostToDevice));
+  int lr;
+  if (i8) {
+    if ((rc = dev_alloc_t(&d_xq, (size_t)R16 * d)) || (rc = dev_alloc_t(&d_xs, (size_t)R16))) { cleanup(); return rc; }
+    FW_HIP(hipMemset(d_xq, 0, (size_t)R16 * d));
+    fwk::launch_quant_rows(st, d_x, d, m->dec_ln.g, m->dec_ln.b, d_xq, d_xs, R, d, 1);
+    lr = fwd::launch_dec_logits(st, true, d_xq, d_xs, m->logits.wq, m->logits.wscale, nullptr, nullptr, d_out, V, R, V, d);
+  } else {
+    lr = fwd::launch_dec_logits(st, false, d_x, nullptr, m->logits.w, nullptr, m->logits.s1, m->logits.cf, d_out, V, R, V,
+                                d);
+  }
+  hipError_t he = hipSuccess;
+  if (lr == 0) he = hipMemcpyAsync(out, d_out, (size_t)R * V * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  cleanup();
+  if (lr != 0 || he != hipSuccess) {
+    set_error("logits projection test failed: %s", lr ? "unsupported shape" : hipGetErrorString(he));
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
 }
 
 int32_t fw_test_layernorm(fw_model* fm, const float* x, const float* g, const float* b, int32_t rows, int32_t d,

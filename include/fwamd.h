@@ -152,6 +152,24 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
                                       int32_t compute_type, int32_t device_index,
                                       int32_t max_batch, int32_t max_beam, fw_model** out);
 
+/* Decode groups — what CTranslate2's replica pool (inter_threads; transcribe.py:645-657, :689-698) becomes on a
+ * GPU with 288 GB of HBM.  A decode step streams every decoder weight once whatever the number of rows, so the
+ * worker replicas of a device share ONE decode workspace instead of decoding side by side:
+ *   fw_model_set_decode_batch(primary, n_workers * max_batch)  sizes the primary's decode workspace for that many
+ *       chunks (rounded down to whole encoder batches and to what fits in HBM; fw_model_decode_batch reads it back);
+ *   fw_model_join_decoder(worker, primary)  frees the worker's own decode workspace and routes its fw_generate /
+ *       fw_detect_language / fw_align calls to the primary's.
+ * fw_generate calls with identical options that arrive from different host threads while a decode run is in
+ * progress are merged into the next run (up to decode_batch chunks); each caller gets exactly the result it would
+ * get alone.  Encoders keep running per worker on their own streams and overlap with the running decode. */
+int32_t fw_model_set_decode_batch(fw_model* m, int32_t decode_batch);
+int32_t fw_model_decode_batch(const fw_model* m);
+int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
+/* counters of the decode group `m` belongs to: decode runs, fw_generate calls served, chunks decoded, chunks of
+ * the largest run (any pointer may be NULL) */
+int32_t fw_model_decode_stats(const fw_model* m, int64_t* runs, int64_t* requests, int64_t* chunks,
+                              int32_t* max_run_chunks);
+
 /* Host image of the device weight blob (what rank 0 broadcasts over RCCL/xGMI at load):
  * fw_pack_blob_size packs and returns a handle + byte size, fw_pack_blob_copy copies the
  * image into caller memory, fw_pack_blob_free releases the handle. */
@@ -246,6 +264,16 @@ int32_t fw_dev_upload(fw_model* m, void* dst_dev, const void* src_host, int64_t 
  * operating on host buffers, so each kernel is parity-tested in isolation) -- */
 int32_t fw_test_gemm(fw_model* m, const float* A, const float* W, const float* bias, const float* residual,
                      int32_t M, int32_t N, int32_t K, int32_t act_gelu, int32_t use_int8, float* out);
+/* one decoder linear exactly as a decode step runs it (fragment-major operands, LayerNorm folded when ln_g/ln_b are
+ * given, GELU when act = 1, residual added last): x [R][K], W [N][K], bias [N] | NULL, res [R][N] | NULL ->
+ * out [R][N] (row-major result) and out_from_frag [R][N] (the fragment-major copy the next linear reads, un-permuted
+ * on the host).  use_int8: the int8_float16 form (needs an int8_float16 model; ln must be NULL). */
+int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const float* bias, const float* ln_g,
+                           const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
+                           int32_t use_int8, float* out, float* out_from_frag);
+/* the vocabulary projection of a decode step: x [R][d] raw residual rows -> float32 logits [R][n_vocab] (final
+ * LayerNorm folded in fp16 mode, applied by the row quantiser in int8_float16 mode), with the model's own weights */
+int32_t fw_test_dec_logits(fw_model* m, const float* x, int32_t R, float* out);
 int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const float* b,
                           int32_t rows, int32_t d, float* out);
 int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,

@@ -4,6 +4,7 @@ Lets the SAME host code (faster_whisper_amd.transcribe: batched pipeline, sequen
 fallback, word timestamps) run once on the HIP engine and once on the CPU restatement, so the GPU tests compare
 whole transcriptions and not only single backend calls.  CPU only, slow, never imported by the product.
 """
+import itertools
 from typing import List, Sequence
 
 import numpy as np
@@ -30,6 +31,7 @@ class OracleBackend:
         self.n_mels = cfg.n_mels
         self.device, self.device_index = "cpu", [0]
         self._lang_names = language_token_strings(cfg)
+        self._seed_counter = itertools.count(1)   # mirrors backend.Whisper: one seed per sampling call
 
     def log_mel_full(self, pcm):
         return olm.log_mel_full(np.asarray(pcm, dtype=np.float32), self.n_mels)
@@ -47,7 +49,10 @@ class OracleBackend:
         return _Enc(self.oracle.encode(f))
 
     def generate(self, enc, prompts: List[List[int]], **kw):
+        from faster_whisper_amd.backend import call_seed
         kw.pop("asynchronous", None)
+        if kw.get("seed") is None:
+            kw["seed"] = call_seed(next(self._seed_counter))
         return self.oracle.generate(enc.array, prompts, **kw)
 
     def detect_language(self, enc):

@@ -530,7 +530,8 @@ def _gumbel(seed: int, row: int, step: int, n: int) -> np.ndarray:
     h ^= h >> np.uint64(13)
     h = (h * np.uint64(0xC2B2AE35)) & M
     h ^= h >> np.uint64(16)
-    u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    # 23 bits keep u strictly inside (0, 1) in float32 (see gumbel_noise in dec_kernels.hip)
+    u = ((h >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
     return (-np.log(-np.log(u))).astype(np.float32)
 
 

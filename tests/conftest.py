@@ -56,3 +56,57 @@ def bench_audio(n_samples=480000, seed=0):
     for f in (220.0, 440.0, 880.0):
         x += 0.05 * np.sin(2 * np.pi * f * t)
     return x.astype(np.float32)
+
+
+def frag_perm(w, ke=32):
+    """MFMA-fragment-major storage of a [N][K] operand (N % 16 == 0): element (n, k) at
+    ((n/16 * K/ke + k/ke) * 64 + 16*((k/(ke/4))%4) + n%16) * (ke/4) + k%(ke/4); ke = 32 (fp16) or 64 (int8)."""
+    n_rows, k_cols = w.shape
+    octet = ke // 4
+    n, k = np.meshgrid(np.arange(n_rows), np.arange(k_cols), indexing="ij")
+    off = (((n >> 4) * (k_cols // ke) + k // ke) * 64 + ((k // octet) & 3) * 16 + (n & 15)) * octet + (k % octet)
+    out = np.empty(n_rows * k_cols, dtype=w.dtype)
+    out[off.reshape(-1)] = w.reshape(-1)
+    return out.reshape(n_rows, k_cols)
+
+
+def frag_unperm(t, ke=32):
+    """inverse of frag_perm"""
+    n_rows, k_cols = t.shape
+    octet = ke // 4
+    n, k = np.meshgrid(np.arange(n_rows), np.arange(k_cols), indexing="ij")
+    off = (((n >> 4) * (k_cols // ke) + k // ke) * 64 + ((k // octet) & 3) * 16 + (n & 15)) * octet + (k % octet)
+    return t.reshape(-1)[off.reshape(-1)].reshape(n_rows, k_cols)
+
+
+def forced_score(oracle, enc_np_b, prompt, ids, kw):
+    """the oracle's score of a GIVEN token sequence under the same decoding rules (teacher forcing through its
+    greedy path): cum log-prob / len^length_penalty exactly as a finished hypothesis is scored.  A sequence shorter
+    than the budget ended with <eot>."""
+    from oracle.whisper import max_new_tokens
+    budget = max_new_tokens(kw.get("max_length", 448), len(prompt))
+    forced = list(ids) + ([oracle.cfg.eot] if len(ids) < budget else [])
+    k2 = {k: v for k, v in kw.items() if k not in ("beam_size", "patience", "num_hypotheses")}
+    r = oracle.generate(enc_np_b[None] if enc_np_b.ndim == 2 else enc_np_b, [list(prompt)], beam_size=1,
+                        force_tokens=[forced], **k2)[0]
+    assert r.sequences_ids[0] == list(ids), (r.sequences_ids[0], ids)
+    return r.scores[0]
+
+
+def check_hypothesis(oracle, enc_np_b, prompt, got, ref, kw, tol=1e-3, gap=2e-2, what=""):
+    """Parity criterion for one chunk of a beam-search (or greedy) result — never skipped, never "most of the time":
+      1. the engine's reported score equals the ORACLE's score of the engine's own token sequence within `tol`
+         (relative to max(1, |score|): the north-star 1e-3 on log-probs), whatever the search path was;
+      2. the engine's sequence IS the oracle's, or the two are tied within `gap` under the oracle's own scoring
+         (a different winner of a numerically tied search is fp16 noise; a worse hypothesis is a bug).
+    Returns True when the ids are identical."""
+    ids = got.sequences_ids[0]
+    s_forced = forced_score(oracle, enc_np_b, prompt, ids, kw)
+    s_got, s_ref = got.scores[0], ref.scores[0]
+    same = ids == ref.sequences_ids[0]
+    print(f"{what}: ids equal={same} engine score {s_got:.5f}, oracle score of the engine's ids {s_forced:.5f}, "
+          f"oracle's best {s_ref:.5f}")
+    assert abs(s_got - s_forced) < tol * max(1.0, abs(s_forced)), (what, s_got, s_forced)
+    if not same:
+        assert abs(s_forced - s_ref) < gap * max(1.0, abs(s_ref)), (what, ids, ref.sequences_ids[0], s_forced, s_ref)
+    return same

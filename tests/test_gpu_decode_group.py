@@ -1,0 +1,136 @@
+"""Decode groups (include/fwamd.h: fw_model_set_decode_batch / fw_model_join_decoder): the worker replicas of a
+device share one decode workspace and concurrent generate() calls are merged into one decode run.  A merged run
+must return, for every caller, EXACTLY what that caller gets alone — every kernel of a step works per row or per
+chunk, so the comparison is bit-exact (ids and scores)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import bench_audio
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name, workers, compute_type="float16", max_batch=3):
+    from faster_whisper_amd import Whisper, get_config, synthetic_weights
+    cfg = get_config(name)
+    w = synthetic_weights(cfg, seed=21)
+    m = Whisper(f"synthetic:{name}", device="cuda", files={"config": cfg, "weights": w}, compute_type=compute_type,
+                max_batch_size=max_batch, max_beam_size=5, inter_threads=workers)
+    return cfg, m
+
+
+def _batches(n, per):
+    return [[bench_audio(480000 if (i + j) % 3 else 250000, seed=50 + 10 * i + j) for j in range(per)] for i in range(n)]
+
+
+@pytest.mark.parametrize("name,compute_type", [("micro", "float16"), ("tiny.en", "float16"), ("micro", "int8_float16")])
+def test_merged_runs_equal_solo_runs(name, compute_type):
+    W = 4
+    cfg, model = _model(name, W, compute_type)
+    st = model.decode_stats()
+    assert st["decode_batch"] == W * 3
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    sup = [cfg.sot, cfg.no_speech, 1, 2]
+    kw = dict(beam_size=5, patience=1.0, length_penalty=1.0, max_length=len(prompt) + 10, suppress_tokens=sup,
+              return_scores=True, return_no_speech_prob=True)
+    batches = _batches(W, 3)
+    batches[2] = batches[2][:2]                       # a smaller batch rides along
+    # solo: one call at a time from this thread
+    solo = [model.generate(model.encode_pcm(b), [prompt] * len(b), **kw) for b in batches]
+    runs0 = model.decode_stats()["runs"]
+    # concurrent: W host threads (one worker replica each) encode, then meet at a barrier and call generate together.
+    # One more thread keeps an encode in flight meanwhile, so the leader of the run waits for the others to arrive.
+    out = [None] * W
+    encs = [None] * W
+    bar = threading.Barrier(W)
+    errs = []
+
+    def work(i):
+        try:
+            encs[i] = model.encode_pcm(batches[i])
+            bar.wait()
+            out[i] = model.generate(encs[i], [prompt] * len(batches[i]), **kw)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    stop = threading.Event()
+
+    def keep_encoding():
+        while not stop.is_set():
+            model.encode_pcm(batches[0][:1])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(W)]
+    bg = threading.Thread(target=keep_encoding)
+    for t in ts:
+        t.start()
+    bg.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    bg.join()
+    assert not errs, errs
+    st = model.decode_stats()
+    print(f"[{name} {compute_type}] {W} concurrent calls -> {st['runs'] - runs0} decode runs, largest run "
+          f"{st['max_run_chunks']} chunks")
+    assert st["max_run_chunks"] > 3                   # at least two calls shared a run
+    for i in range(W):
+        for a, b in zip(out[i], solo[i]):
+            assert a.sequences_ids == b.sequences_ids
+            assert a.scores == b.scores
+            assert a.no_speech_prob == b.no_speech_prob
+
+
+def test_mixed_options_are_not_merged_and_sampling_runs_alone():
+    cfg, model = _model("micro", 3)
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    prompt_ts = list(cfg.sot_sequence)
+    batches = _batches(3, 2)
+    kws = [dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True),
+           dict(beam_size=2, max_length=len(prompt) + 8, return_scores=True),
+           dict(beam_size=1, num_hypotheses=3, sampling_topk=0, sampling_temperature=0.7, seed=5,
+                max_length=len(prompt) + 8, return_scores=True)]
+    prompts = [prompt, prompt_ts, prompt]
+    solo = [model.generate(model.encode_pcm(b), [p] * len(b), **kw) for b, p, kw in zip(batches, prompts, kws)]
+    out = [None] * 3
+    bar = threading.Barrier(3)
+
+    def work(i):
+        e = model.encode_pcm(batches[i])
+        bar.wait()
+        out[i] = model.generate(e, [prompts[i]] * len(batches[i]), **kws[i])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(3):
+        for a, b in zip(out[i], solo[i]):
+            assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
+
+
+def test_detect_language_and_align_through_a_worker():
+    """decode-side calls of a worker replica run on the group's workspace"""
+    from faster_whisper_amd.backend import StorageView
+    cfg, model = _model("micro", 2)
+    cfg1, single = _model("micro", 1)
+    chunks = _batches(1, 3)[0]
+    res = []
+
+    def work():
+        e = model.encode_pcm(chunks)                   # second thread -> second replica
+        res.append((model.detect_language(e), model.align(e, cfg.sot_sequence, [[11, 12, 13]] * 3, [3000] * 3)))
+
+    t = threading.Thread(target=work)
+    model.encode_pcm(chunks[:1])                       # pins replica 0 to this thread
+    t.start()
+    t.join()
+    e1 = single.encode_pcm(chunks)
+    lang1 = single.detect_language(e1)
+    al1 = single.align(e1, cfg.sot_sequence, [[11, 12, 13]] * 3, [3000] * 3)
+    lang, al = res[0]
+    assert lang == lang1
+    for a, b in zip(al, al1):
+        assert a.alignments == b.alignments and a.text_token_probs == b.text_token_probs

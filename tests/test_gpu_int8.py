@@ -7,7 +7,7 @@ tolerances are those of the fp16 tests, loosened where a flipped code is visible
 import numpy as np
 import pytest
 
-from conftest import bench_audio, make_model
+from conftest import bench_audio, check_hypothesis, make_model
 
 pytestmark = pytest.mark.gpu
 
@@ -82,6 +82,31 @@ def test_gemm_int8_transposed_epilogue(kmodel, M, N, K):
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-3
 
 
+@pytest.mark.parametrize("R,N,K", [(80, 1280, 1280), (80, 5120, 1280), (80, 1280, 5120), (77, 3840, 1280),
+                                   (5, 128, 128), (333, 256, 512), (640, 1280, 1280)])
+def test_dec_linear_int8_exact(kmodel, R, N, K):
+    """the int8 decoder linear of a decode step (row quantiser writing fragment-major + v_mfma_i32_16x16x64_i8
+    register-streaming GEMM) against the exact integer reference, at the large-v3 step shapes"""
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(R + N + K)
+    x = _h(rng.standard_normal((R, K)).astype(np.float32))
+    x[min(3, R - 1)] = 0.0
+    W = _h((rng.standard_normal((N, K)) * (0.2 + np.arange(N)[:, None] / N)).astype(np.float32))
+    b = _h(rng.standard_normal(N).astype(np.float32))
+    r = _h(rng.standard_normal((R, N)).astype(np.float32))
+    out = np.empty((R, N), np.float32)
+    out2 = np.empty((R, N), np.float32)
+    _lib.check(lib.fw_test_dec_linear(kmodel._replicas[0].handle, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), None, None,
+                                      _lib.ptr(r), R, N, K, 0, 1, _lib.ptr(out), _lib.ptr(out2)))
+    xq, x_s = _quant_rows(x)
+    wq, w_s = _quant_rows(W)
+    ref = _h((xq @ wq.T).astype(np.float32) * x_s[:, None] * w_s[None, :] + b + r)
+    err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+    print(f"int8 dec linear {R}x{N}x{K}: rel err vs integer reference {err:.2e}")
+    assert err < 1e-3
+
+
 @pytest.fixture(scope="module", params=["micro", "tiny.en"])
 def setup(request):
     from oracle.whisper import OracleWhisper
@@ -146,20 +171,17 @@ def test_generate_int8(setup, beam):
               max_initial_timestamp_index=50)
     got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
     ref = oracle.generate(enc_np, [prompt] * 3, **kw)
-    same = 0
     for b, (g, r) in enumerate(zip(got, ref)):
-        eq = g.sequences_ids[0] == r.sequences_ids[0]
-        same += eq
-        print(f"[{cfg.name}] int8 beam={beam} chunk {b}: equal={eq} score {g.scores[0]:.5f} vs {r.scores[0]:.5f}")
         if beam == 1:
             n = 0
             while n < len(r.margins) and n < len(r.sequences_ids[0]) and r.margins[n] > MARGIN:
                 n += 1
             assert g.sequences_ids[0][:n] == r.sequences_ids[0][:n]
-        if eq:
-            assert abs(g.scores[0] - r.scores[0]) < 5e-3 * max(1.0, abs(r.scores[0]))
+        # score of the engine's own ids under the oracle always within 5e-3 (a flipped int8 code is visible);
+        # different ids only when the two hypotheses are tied within 4e-2 under the oracle's scoring
+        check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, tol=5e-3, gap=4e-2,
+                         what=f"[{cfg.name}] int8 beam={beam} chunk {b}")
         assert abs(g.no_speech_prob - r.no_speech_prob) < 2e-3
-    assert same >= 1   # low-margin flips are more frequent than in fp16; the margin-safe prefix above is the gate
 
 
 def test_int8_tracks_float16(setup):

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def model():
     cfg, w, m = make_model("micro", max_batch=2, max_beam=2)
+    m._test_weights = w
     return m
 
 
@@ -130,3 +131,88 @@ def test_encoder_attention(model, B, H, T):
     err = np.abs(out - ref).max()
     print(f"attention B={B} H={H} T={T}: abs err {err:.2e}")
     assert err < 5e-3
+
+
+# ---- decoder-step linears: the fragment-major register-streaming GEMM exactly as a decode step launches it ----
+def _dec_linear(model, x, W, bias=None, ln=None, res=None, act=0, int8=False):
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    R, K = x.shape
+    N = W.shape[0]
+    out = np.empty((R, N), np.float32)
+    out_frag = np.empty((R, N), np.float32)
+    f = lambda a: _lib.ptr(np.ascontiguousarray(a, np.float32)) if a is not None else None   # noqa: E731
+    keep = [np.ascontiguousarray(a, np.float32) if a is not None else None
+            for a in (x, W, bias, ln[0] if ln else None, ln[1] if ln else None, res)]
+    ptrs = [_lib.ptr(a) if a is not None else None for a in keep]
+    _lib.check(lib.fw_test_dec_linear(model._replicas[0].handle, *ptrs, R, N, K, act, int(int8), _lib.ptr(out),
+                                      _lib.ptr(out_frag)))
+    return out, out_frag
+
+
+def _ln_ref(x, g, b):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + 1e-5) * g + b
+
+
+# (R, N, K): the shapes of a large-v3 decode step at 16 chunks x beam 5 (80 rows: out-proj / cross-q, ffn1, ffn2 —
+# K = 5120 runs the 8-wave instantiation and two load chunks per wave), a ragged row count with the fused-QKV
+# width, a single row tile, and the row counts of merged decode runs (160 .. 640 rows: row groups on grid.y)
+DEC_SHAPES = [(80, 1280, 1280), (80, 5120, 1280), (80, 1280, 5120), (77, 3840, 1280), (5, 128, 128), (16, 384, 1536),
+              (160, 1280, 1280), (333, 256, 512), (640, 1280, 5120)]
+
+
+@pytest.mark.parametrize("R,N,K", DEC_SHAPES)
+def test_dec_linear_plain_bias_residual(model, R, N, K):
+    rng = np.random.default_rng(R + N + K)
+    x = _h(rng.standard_normal((R, K)).astype(np.float32))
+    W = _h((rng.standard_normal((N, K)) * (0.5 + np.arange(N)[:, None] / N) / np.sqrt(K)).astype(np.float32))
+    b = _h(0.1 * rng.standard_normal(N).astype(np.float32))
+    r = _h(rng.standard_normal((R, N)).astype(np.float32))
+    ref = x @ W.T + b + r
+    out, out_frag = _dec_linear(model, x, W, bias=b, res=r)
+    err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+    print(f"dec linear {R}x{N}x{K} bias+res: rel err {err:.2e}")
+    assert err < 2e-3
+    assert np.array_equal(out, out_frag)       # the fragment-major copy is the same tensor
+
+
+@pytest.mark.parametrize("R,N,K", [s for s in DEC_SHAPES if s[2] <= 1536])
+def test_dec_linear_layernorm_folded_gelu(model, R, N, K):
+    """qkv / cross-q / ffn1 form: LayerNorm folded into the weights (y = rstd*(W.g x - mu*s1) + cf), exact GELU"""
+    rng = np.random.default_rng(R * 3 + N + K)
+    x = _h((rng.standard_normal((R, K)) * 1.7 + 0.3).astype(np.float32))
+    x[R // 2] *= 8.0                                   # one row with a very different scale
+    x = _h(x)
+    W = _h((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = _h(0.1 * rng.standard_normal(N).astype(np.float32))
+    g = _h(1 + 0.1 * rng.standard_normal(K).astype(np.float32))
+    lb = _h(0.05 * rng.standard_normal(K).astype(np.float32))
+    for act in (0, 1):
+        base = _ln_ref(x.astype(np.float64), g, lb) @ W.T.astype(np.float64) + b
+        ref = _gelu(base) if act else base
+        out, out_frag = _dec_linear(model, x, W, bias=b, ln=(g, lb), act=act)
+        err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+        print(f"dec linear {R}x{N}x{K} LN-folded act={act}: rel err {err:.2e}")
+        assert err < 4e-3
+        assert np.array_equal(out, out_frag)
+
+
+@pytest.mark.parametrize("R", [1, 5, 16, 48, 64, 80, 83, 640])
+def test_dec_logits_projection(model, R):
+    """the vocabulary projection of a decode step (full-K-per-wave kernel, final LayerNorm folded) against fp64 on
+    the model's own weights; R covers every row-tile instantiation and the row groups of merged runs"""
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    cfg = model.config
+    w = model._test_weights
+    rng = np.random.default_rng(R)
+    x = _h((rng.standard_normal((R, cfg.d_model)) * 2 + 0.5).astype(np.float32))
+    out = np.empty((R, cfg.n_vocab), np.float32)
+    _lib.check(lib.fw_test_dec_logits(model._replicas[0].handle, _lib.ptr(x), R, _lib.ptr(out)))
+    E = w["dec.tok_emb"].astype(np.float64)
+    ref = _ln_ref(x.astype(np.float64), w["dec.ln.g"].astype(np.float64), w["dec.ln.b"].astype(np.float64)) @ E.T
+    err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+    print(f"dec logits R={R}: rel err {err:.2e}")
+    assert err < 3e-3
