@@ -1,4 +1,4 @@
-// K2/K3/K6/K8-K11 — the dense fp16 MFMA GEMM of the encoder (and of every
+// K2/K3/K6/K8-K11 — the dense fp16 / int8 MFMA GEMM of the encoder (and of every
 // "many rows" linear: conv1d-as-GEMM, fused QKV, out-proj, FFN, cross-K/V projection).
 //
 //   C[z][m][n] = epi( sum_k A[z][m][k] * W[n][k] )      A, W, C fp16; fp32 accumulate
@@ -7,50 +7,73 @@
 // Both operands are K-contiguous ("B^T" form), which is the natural MFMA fragment
 // order: lane (row = l&31, k-octet = l>>5) reads 16 contiguous bytes.
 //
-// gfx950 mapping
-//  * 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
-//    v_mfma_f32_32x32x16_f16 (64 accumulator VGPRs).
-//  * global -> LDS by direct DMA (global_load_lds, 16 B/lane, coalesced 128 B rows, no VGPR
-//    round trip) -> MFMA fragments (ds_read_b128). LDS rows are 128 B; the 16-byte chunk
-//    index is XOR-swizzled with (row>>1)&7 (applied to the DMA source address, the LDS
-//    image itself is lane-linear), which makes every ds_read_b128 lane group
-//    conflict-free (MI355X_MICROARCH.md LDS table).
-//  * double-buffered LDS, ONE barrier per K tile; the next tile's DMA is issued right
-//    after that barrier and lands while the current tile is multiplied.
-//  * normal mode computes D = W_tile * A_tile^T so that each lane ends up with four
-//    consecutive n of one row m -> 8-byte stores; TRANS mode computes D = A_tile *
-//    W_tile^T, each lane holds four consecutive m of one column n, and the tile is
-//    stored transposed (Ct[z][n][m]) — used to emit V^T for the attention kernels
-//    without a separate transpose pass.
-//  * conv1d (k=3, stride s) over a channel-last, zero-padded image is this GEMM with
-//    lda = s*C and K = 3*C: the three taps of an output row are contiguous in memory.
-//  * 1-D grid with a bijective XCD remap; n fastest inside an m panel so the blocks
-//    resident on one XCD share the A panel and the whole W in that XCD's L2.
+// gfx950 mapping (MI355X_MICROARCH.md / cdna_hip_programming.md section 5: what lifts a GEMM past the 128x128
+// two-barrier structure is the depth of the staging pipeline, not the tile alone)
+//  * 256 x 256 x 128-byte block tile (64 halves or 128 int8 of K), 8 waves as 2 (M) x 4 (N), each wave
+//    128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x16_f16 / v_mfma_i32_32x32x32_i8 (128 accumulator registers);
+//    one workgroup per CU, 128 KB of LDS.
+//  * HBM/L2 -> LDS by direct DMA (global_load_lds, 16 B per lane, no VGPR round trip).  A K tile is staged as FOUR
+//    UNITS of 16 KB — A0 / A1 = the first / second 64 rows of every wave row-half, B0 / B1 = the first / second 32
+//    columns of every wave column-quarter — because that is the granularity at which the workgroup consumes it:
+//    a K tile is multiplied in four PHASES of 8 MFMAs per wave,
+//         phase 1: A0 x B0   (reads A0, B0 from LDS into registers)
+//         phase 2: A0 x B1   (reads B1; A0 stays in registers)
+//         phase 3: A1 x B0   (reads A1; B0 stays in registers)
+//         phase 4: A1 x B1   (reads nothing)
+//    so a unit's LDS bytes are dead one to three phases after they were read and can be refilled with the tile
+//    two steps ahead while the current tile is still being multiplied.  One unit (2 DMA instructions per wave)
+//    is issued per phase:   phase 1: B1(t+1)   phase 2: A1(t+1)   phase 3: B0(t+2)   phase 4: A0(t+2)
+//    which puts every unit 5-6 phases (>= 1300 cycles of MFMA work) ahead of its first read, and ONE counted wait,
+//    s_waitcnt vmcnt(8) at the end of every load segment, retires exactly the unit that the NEXT phase reads (the
+//    four younger units stay in flight across the barriers; the queue is never drained inside the K loop).
+//  * The 8 waves run as two groups (wave row 0 / wave row 1 = the two waves of every SIMD) staggered by half a
+//    phase: each phase is  [load segment: ds_read fragments, issue DMA, counted wait] barrier [compute segment: 8
+//    MFMAs] barrier,  and group 1 enters the loop one barrier late, so on every SIMD one wave multiplies while
+//    the other loads.  RAW / WAR of the DMA ring under that stagger: a unit is read one phase after the wait that
+//    retires it (all 8 waves have passed their wait and a barrier), and refilled two phases after its last read.
+//  * LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 — applied to the DMA SOURCE
+//    address, the LDS image itself is lane-linear — which makes every ds_read_b128 lane group conflict-free.
+//  * normal mode computes D = W_tile * A_tile^T so that each lane ends up with four consecutive n of one row m ->
+//    8-byte stores; TRANS mode computes D = A_tile * W_tile^T, each lane holds four consecutive m of one column
+//    n, and the tile is stored transposed (Ct[z][n][m]) — used to emit V^T for the attention kernels without a
+//    separate transpose pass.
+//  * conv1d (k=3, stride s) over a channel-last, zero-padded image is this GEMM with lda = s*C and K = 3*C: the
+//    three taps of an output row are contiguous in memory.
+//  * 1-D grid with a bijective XCD remap; n fastest inside an m panel so the blocks resident on one XCD share
+//    the A panel and the whole W in that XCD's L2.
 #include "common.h"
 #include "kernels.h"
 
-#define GB_M 128
-#define GB_N 128
-#define GB_K 64
-#define GB_TILE_HALVES (128 * 64)
+#define GB_M 256
+#define GB_N 256
+#define GB_UNIT_BYTES (128 * 128)          // one staging unit: 128 rows x 128 B
+#define GB_SLOT_BYTES (4 * GB_UNIT_BYTES)  // one K tile: A0, A1, B0, B1
+#define GB_LDS_BYTES (2 * GB_SLOT_BYTES)   // two K tiles in the ring
 
 typedef int intx16 __attribute__((ext_vector_type(16)));
+
+// workgroup barrier that the compiler may not move LDS reads or DMA issues across (the raw builtin carries no fence;
+// the counted vmcnt protocol below is what orders the DMA ring, so no vmcnt(0) drain is wanted here)
+#define GB_BARRIER()                      \
+  do {                                    \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();         \
+    asm volatile("" ::: "memory");         \
+  } while (0)
 
 // I8: the int8_float16 path (K25): A and W are int8 (per-row dequant scales a_scale[m], w_scale[n]),
 // v_mfma_i32_32x32x32_i8 accumulates in int32, the epilogue de-quantises.  The tile is defined in BYTES
 // (128-byte rows = 64 halves or 128 int8), so staging, swizzle and fragment reads are shared.
 template <bool TRANS, bool I8>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
+__global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int ES = I8 ? 1 : 2;        // element size
-  constexpr int TILE_BYTES = 128 * 128;
-  char* sA = smem_raw;                  // [2][128 rows][128 B]
-  char* sW = smem_raw + 2 * TILE_BYTES; // [2][128 rows][128 B]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;
 
   const int per_z = p.nMt * p.nNt;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -61,90 +84,128 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
 
   const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)z * p.a_bstride * ES;
   const char* Wb = reinterpret_cast<const char*>(p.W);
-  // staging: direct HBM/L2 -> LDS DMA (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write
-  // pass).  A wave instruction fills 64 consecutive 16-byte LDS slots = 8 tile rows; the LDS image must
-  // stay lane-linear, so the XOR swizzle is applied to the SOURCE address: LDS slot (row, c') receives
-  // global chunk c = c' ^ ((row >> 1) & 7)  (the fragment reads below apply the same involution).
-  const int wuni = __builtin_amdgcn_readfirstlane(wave);
-  const char* gA[4];
-  const char* gW[4];
+
+  // ---- staging addresses.  A wave DMA instruction fills 64 consecutive 16-byte LDS slots = 8 unit rows; wave w
+  // issues pieces w and w + 8 of a unit (unit rows 8*piece .. +7).  Unit row u of A0 is tile row (u>>6)*128 + (u&63)
+  // (+64 for A1); of B0 tile column (u>>5)*64 + (u&31) (+32 for B1).  LDS slot (u, c') receives global chunk
+  // c = c' ^ ((u >> 1) & 7); the fragment reads below apply the same involution. ----
+  const char* gsrc[4][2];   // [unit: A0, A1, B0, B1][piece]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wuni) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    int am = m0 + row; if (am > p.M - 1) am = p.M - 1;
-    int wn_ = n0 + row; if (wn_ > p.N - 1) wn_ = p.N - 1;
-    gA[i] = Ab + (size_t)am * p.lda * ES + c * 16;
-    gW[i] = Wb + (size_t)wn_ * p.ldw * ES + c * 16;
+  for (int i = 0; i < 2; ++i) {
+    const int u = (i * 8 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((u >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int am = m0 + (u >> 6) * 128 + (u & 63) + h * 64; if (am > p.M - 1) am = p.M - 1;
+      int wr = n0 + (u >> 5) * 64 + (u & 31) + h * 32; if (wr > p.N - 1) wr = p.N - 1;
+      gsrc[h][i] = Ab + (size_t)am * p.lda * ES + c * 16;
+      gsrc[2 + h][i] = Wb + (size_t)wr * p.ldw * ES + c * 16;
+    }
   }
   const int nk = p.K * ES / 128;
-  auto stage = [&](int kt, int buf) {
+  auto issue = [&](int unit, int kt) {   // 2 DMA instructions per wave
+    char* dst = smem_raw + (kt & 1) * GB_SLOT_BYTES + unit * GB_UNIT_BYTES;
     const int koff = kt * 128;
-    char* dA = sA + buf * TILE_BYTES;
-    char* dW = sW + buf * TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + koff),
-                                       (__attribute__((address_space(3))) void*)(dA + (i * 4 + wuni) * 1024), 16, 0,
-                                       0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW[i] + koff),
-                                       (__attribute__((address_space(3))) void*)(dW + (i * 4 + wuni) * 1024), 16, 0,
-                                       0);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[unit][i] + koff),
+                                       (__attribute__((address_space(3))) void*)(dst + (i * 8 + wave) * 1024), 16, 0, 0);
   };
-  stage(0, 0);
 
-  floatx16 accf[2][2];
-  intx16 acci[2][2];
+  floatx16 accf[4][2];
+  intx16 acci[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { accf[i][j] = floatx16{0}; acci[i][j] = intx16{0}; }
 
-  // fragment rows and their swizzle keys
-  int arow[2], wrow[2];
+  // fragment read offsets inside a unit (bytes, without the k-chunk): row * 128, and the row's swizzle key
+  int arow[2], akey[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    arow[i] = wm * 64 + i * 32 + l31;
-    wrow[i] = wn * 64 + i * 32 + l31;
+    const int u = wm * 64 + i * 32 + l31;
+    arow[i] = u * 128;
+    akey[i] = (u >> 1) & 7;
   }
+  const int bu = wn * 32 + l31;
+  const int brow = bu * 128, bkey = (bu >> 1) & 7;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    // tile kt has landed (this wave's DMAs drained, then the barrier covers the other waves'); the same
-    // barrier proves every wave is done reading buffer cur^1, which the next tile's DMA overwrites while
-    // this tile is multiplied.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const char* cA = sA + cur * TILE_BYTES;
-    const char* cW = sW + cur * TILE_BYTES;
+  intx4 fa[2][4], fb0[4], fb1[4];
+  auto read_a = [&](const char* unit) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = ks * 2 + hi;
-      intx4 fa[2], fw[2];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        fa[i][ks] = *reinterpret_cast<const intx4*>(unit + arow[i] + (((ks * 2 + hi) ^ akey[i]) << 4));
+  };
+  auto read_b = [&](const char* unit, intx4 (&fb)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const intx4*>(unit + brow + (((ks * 2 + hi) ^ bkey) << 4));
+  };
+  // 8 MFMAs: the two row tiles of A half `ah` (registers fa) x column tile `ni`
+  auto mma = [&](int ah, int ni, const intx4 (&fb)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const intx4*>(cA + arow[i] * 128 + ((chunk ^ ((arow[i] >> 1) & 7)) << 4));
-        fw[i] = *reinterpret_cast<const intx4*>(cW + wrow[i] * 128 + ((chunk ^ ((wrow[i] >> 1) & 7)) << 4));
+        const int mi = ah * 2 + i;
+        // TRANS: D[m][n];  else D[n][m]  (both accumulate into acc[mi][ni])
+        const intx4 opa = TRANS ? fa[i][ks] : fb[ks];
+        const intx4 opb = TRANS ? fb[ks] : fa[i][ks];
+        if (I8) acci[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(opa, opb, acci[mi][ni], 0, 0, 0);
+        else accf[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, opa),
+                                                                 __builtin_bit_cast(half8_t, opb), accf[mi][ni], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // TRANS: D[m][n] -> acc[mi][ni];  else D[n][m] -> acc[ni][mi]
-          const intx4 opa = TRANS ? fa[i] : fw[i];
-          const intx4 opb = TRANS ? fw[j] : fa[j];
-          if (I8) {
-            acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(opa, opb, acci[i][j], 0, 0, 0);
-          } else {
-            accf[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, opa),
-                                                              __builtin_bit_cast(half8_t, opb), accf[i][j], 0, 0, 0);
-          }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // end of a load segment: retire the unit the next phase reads (everything but the four youngest units); when
+  // this phase had nothing left to issue the queue is shorter than the count assumes, so drain it
+  auto seg_wait = [&](bool issued) {
+    if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // ---- prologue: tile 0 whole, tile 1's B0 / A0 (the issue order of the steady state) ----
+  issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
+  if (nk > 1) { issue(2, 1); issue(0, 1); }
+  seg_wait(nk > 1);
+  GB_BARRIER();
+  if (wm == 1) GB_BARRIER();   // group 1 runs half a phase behind group 0
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* slot = smem_raw + (kt & 1) * GB_SLOT_BYTES;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // phase 1: A0 x B0
+    read_a(slot);
+    read_b(slot + 2 * GB_UNIT_BYTES, fb0);
+    if (n1) issue(3, kt + 1);
+    seg_wait(n1);
+    GB_BARRIER();
+    mma(0, 0, fb0);
+    GB_BARRIER();
+    // phase 2: A0 x B1
+    read_b(slot + 3 * GB_UNIT_BYTES, fb1);
+    if (n1) issue(1, kt + 1);
+    seg_wait(n1);
+    GB_BARRIER();
+    mma(0, 1, fb1);
+    GB_BARRIER();
+    // phase 3: A1 x B0
+    read_a(slot + GB_UNIT_BYTES);
+    if (n2) issue(2, kt + 2);
+    seg_wait(n2);
+    GB_BARRIER();
+    mma(1, 0, fb0);
+    GB_BARRIER();
+    // phase 4: A1 x B1
+    if (n2) issue(0, kt + 2);
+    seg_wait(n2);
+    GB_BARRIER();
+    mma(1, 1, fb1);
+    GB_BARRIER();
   }
+  if (wm == 0) GB_BARRIER();   // the barrier group 1 spent on the stagger
 
   // ---------------------------------- epilogue ----------------------------------
   const float* sa = I8 ? p.a_scale + (size_t)z * p.as_bstride : nullptr;
@@ -154,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31;
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 128 + mi * 32 + l31;
         if (m >= p.M) continue;
         const float sam = I8 ? sa[m] : 1.f;
 #pragma unroll
@@ -165,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            v[e] = I8 ? (float)acci[ni][mi][g * 4 + e] * sam * p.w_scale[n + e] : accf[ni][mi][g * 4 + e];
+            v[e] = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
           if (p.bias) {
             const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + n);
 #pragma unroll
@@ -200,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
   } else {
     half_t* Cb = p.C + (size_t)z * p.c_bstride;  // Ct[z][n][m], ldc = row stride of Ct
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int n = n0 + wn * 64 + ni * 32 + l31;
@@ -209,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(fwk::GemmParams p) {
         const float swn = I8 ? p.w_scale[n] : 1.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int m = m0 + wm * 64 + mi * 32 + 8 * g + 4 * hi;
+          const int m = m0 + wm * 128 + mi * 32 + 8 * g + 4 * hi;
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -252,7 +313,7 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   if (i8 && !p.w_scale) return -1;
   p.nMt = (p.M + GB_M - 1) / GB_M;
   p.nNt = (p.N + GB_N - 1) / GB_N;
-  const int lds = 4 * 128 * 128;  // 64 KiB
+  const int lds = GB_LDS_BYTES;  // 128 KiB: one workgroup per CU
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, false>),
@@ -267,11 +328,11 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   }
   const int grid = p.nMt * p.nNt * batch;
   if (i8) {
-    if (trans) gemm_f16_kernel<true, true><<<grid, 256, lds, st>>>(p);
-    else gemm_f16_kernel<false, true><<<grid, 256, lds, st>>>(p);
+    if (trans) gemm_f16_kernel<true, true><<<grid, 512, lds, st>>>(p);
+    else gemm_f16_kernel<false, true><<<grid, 512, lds, st>>>(p);
   } else {
-    if (trans) gemm_f16_kernel<true, false><<<grid, 256, lds, st>>>(p);
-    else gemm_f16_kernel<false, false><<<grid, 256, lds, st>>>(p);
+    if (trans) gemm_f16_kernel<true, false><<<grid, 512, lds, st>>>(p);
+    else gemm_f16_kernel<false, false><<<grid, 512, lds, st>>>(p);
   }
   return 0;
 }

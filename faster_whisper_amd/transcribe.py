@@ -964,113 +964,90 @@ class BatchedInferencePipeline:
             local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         n = len(audio_chunks)
         seg_idx = 0
-        if world == 1:
-            # single process: segments are yielded as soon as their batch is decoded.  With worker replicas
-            # (WhisperModel(num_workers=W) -> backend inter_threads) W batches are kept in flight on the GPU:
-            # the batches of a recording are independent (`condition_on_previous_text=False`), only the
-            # word-timestamp pause heuristics chain through last_speech_timestamp, and those run here, in order.
-            workers = int(getattr(m.model, "inter_threads", 1) or 1)
+        # The batches of a recording are independent (`condition_on_previous_text=False`): with worker replicas
+        # (WhisperModel(num_workers=W) -> backend inter_threads) W batches are kept in flight on the GPU — their
+        # encoders run side by side and their generate() calls share decode runs (backend decode groups).  Only
+        # the word-timestamp pause heuristics chain through last_speech_timestamp; those run in order, below.
+        workers = int(getattr(m.model, "inter_threads", 1) or 1)
 
-            def decode_batch(i):
-                chunks = audio_chunks[i:i + batch_size]
-                feats = None if fused_features else m.model.log_mel(chunks)
-                enc, outs = self.generate_segment_batched(feats, tokenizer, options,
-                                                          audio_chunks=chunks if fused_features else None)
-                local, sizes = self._split_outputs(outs, tokenizer, chunks_metadata[i:i + batch_size])
-                aligned = (m.align_words(local, tokenizer, enc, sizes, options.prepend_punctuations,
-                                         options.append_punctuations) if options.word_timestamps else None)
-                return local, aligned
+        def decode_batch(i0, i1):
+            chunks = audio_chunks[i0:i1]
+            feats = None if fused_features else m.model.log_mel(chunks)
+            enc, outs = self.generate_segment_batched(feats, tokenizer, options,
+                                                      audio_chunks=chunks if fused_features else None)
+            local = aligned = None
+            if world == 1 or options.word_timestamps:
+                local, sizes = self._split_outputs(outs, tokenizer, chunks_metadata[i0:i1])
+                if options.word_timestamps:
+                    # the chunk-local half of the word timing runs where the encoder output lives
+                    aligned = m.align_words(local, tokenizer, enc, sizes, options.prepend_punctuations,
+                                            options.append_punctuations)
+            return outs, local, aligned
 
-            def batches():
-                starts = list(range(0, n, batch_size))
-                if workers <= 1 or len(starts) <= 1:
-                    for i in starts:
-                        yield decode_batch(i)
-                    return
-                from collections import deque
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=workers) as pool:
-                    pending = deque()
-                    for i in starts:
-                        pending.append(pool.submit(decode_batch, i))
-                        if len(pending) >= workers:
-                            yield pending.popleft().result()
-                    while pending:
+        def batches(lo, hi):
+            """(outs, local, aligned) per batch of the chunk range [lo, hi), in order, `workers` batches in flight"""
+            spans = [(i, min(hi, i + batch_size)) for i in range(lo, hi, batch_size)]
+            if workers <= 1 or len(spans) <= 1:
+                for sp in spans:
+                    yield decode_batch(*sp)
+                return
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                pending = deque()
+                for sp in spans:
+                    pending.append(pool.submit(decode_batch, *sp))
+                    if len(pending) >= workers:
                         yield pending.popleft().result()
+                while pending:
+                    yield pending.popleft().result()
 
-            for results, aligned in batches():
+        def emit(results):
+            nonlocal seg_idx
+            for result in results:
+                for seg in result:
+                    seg_idx += 1
+                    yield Segment(seek=seg["seek"], id=seg_idx, text=seg["text"], start=round(seg["start"], 3),
+                                  end=round(seg["end"], 3), tokens=seg["tokens"], avg_logprob=seg["avg_logprob"],
+                                  words=(None if not options.word_timestamps else [Word(**w) for w in seg["words"]]),
+                                  no_speech_prob=seg["no_speech_prob"], compression_ratio=seg["compression_ratio"],
+                                  temperature=options.temperatures[0])
+
+        if world == 1:
+            # single process: segments are yielded as soon as their batch is decoded
+            for _, results, aligned in batches(0, n):
                 if options.word_timestamps:
                     self.last_speech_timestamp = m.apply_word_alignments(results, aligned, self.last_speech_timestamp)
-                for result in results:
-                    for seg in result:
-                        seg_idx += 1
-                        yield Segment(seek=seg["seek"], id=seg_idx, text=seg["text"], start=round(seg["start"], 3),
-                                      end=round(seg["end"], 3), tokens=seg["tokens"], avg_logprob=seg["avg_logprob"],
-                                      words=(None if not options.word_timestamps
-                                             else [Word(**w) for w in seg["words"]]),
-                                      no_speech_prob=seg["no_speech_prob"],
-                                      compression_ratio=seg["compression_ratio"],
-                                      temperature=options.temperatures[0])
+                yield from emit(results)
             self.last_speech_timestamp = 0.0
             return
+        # sharded: every rank decodes its contiguous block of the chunk list (no collective in the data path), then
+        # ONE gather brings the fixed-size result records — and the chunk-local word alignments — to rank 0, in
+        # rank order = the serial order
         bounds = partition(n, world)
         lo, hi = bounds[rank]
         max_len = m.max_length
-        # every rank walks the same number of batch rounds so the per-round gather lines up
-        rounds = max((b[1] - b[0] + batch_size - 1) // batch_size for b in bounds) if n else 0
-        per_rank_outputs = [[] for _ in range(world)]
-        per_rank_aligned = [[] for _ in range(world)]
-        for rnd in range(rounds):
-            i0 = lo + rnd * batch_size
-            i1 = min(hi, i0 + batch_size)
-            outs, aligned = [], []
-            if i0 < i1:
-                chunks = audio_chunks[i0:i1]
-                if fused_features:
-                    enc, outs = self.generate_segment_batched(None, tokenizer, options, audio_chunks=chunks)
-                else:
-                    feats = m.model.log_mel(chunks)
-                    enc, outs = self.generate_segment_batched(feats, tokenizer, options)
-                if options.word_timestamps:
-                    # the chunk-local half of the word timing runs where the encoder output lives; the
-                    # sequential half (pause heuristics chained through last_speech_timestamp) on rank 0 below
-                    local, sizes = self._split_outputs(outs, tokenizer, chunks_metadata[i0:i1])
-                    aligned = m.align_words(local, tokenizer, enc, sizes, options.prepend_punctuations,
-                                            options.append_punctuations)
-            if options.word_timestamps and world > 1:
-                import torch.distributed as dist
-                bucket = [None] * world if rank == 0 else None
-                dist.gather_object(aligned, bucket, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        per_rank_aligned[r].extend(bucket[r])
-            if world == 1:
-                per_rank_outputs[0].extend(outs)
-            else:
-                counts = [max(0, min(b[1], b[0] + (rnd + 1) * batch_size) - (b[0] + rnd * batch_size)) for b in bounds]
-                recs = _OutRec.wrap(outs)
-                got = gather_results(recs, max_len, rank, world, local_rank, counts=counts)
-                if rank == 0:
-                    pos = 0
-                    for r in range(world):
-                        for (ids, avg_lp, nsp) in got[pos:pos + counts[r]]:
-                            per_rank_outputs[r].append(dict(tokens=ids, avg_logprob=avg_lp, no_speech_prob=nsp))
-                        pos += counts[r]
+        my_outs, my_aligned = [], []
+        for outs, _, aligned in batches(lo, hi):
+            my_outs.extend(outs)
+            if options.word_timestamps:
+                my_aligned.extend(aligned)
+        counts = [b[1] - b[0] for b in bounds]
+        ordered_aligned = None
+        if options.word_timestamps:
+            import torch.distributed as dist
+            bucket = [None] * world if rank == 0 else None
+            dist.gather_object(my_aligned, bucket, dst=0)
+            if rank == 0:
+                ordered_aligned = [a for r in range(world) for a in bucket[r]]
+        got = gather_results(_OutRec.wrap(my_outs), max_len, rank, world, local_rank, counts=counts)
         if rank != 0:
             return
-        ordered = [o for r in range(world) for o in per_rank_outputs[r]]
+        ordered = [dict(tokens=ids, avg_logprob=avg_lp, no_speech_prob=nsp) for (ids, avg_lp, nsp) in got]
         results, _ = self._split_outputs(ordered, tokenizer, chunks_metadata)
         if options.word_timestamps:
-            ordered_aligned = [a for r in range(world) for a in per_rank_aligned[r]]
             self.last_speech_timestamp = m.apply_word_alignments(results, ordered_aligned, self.last_speech_timestamp)
-        for result in results:
-            for seg in result:
-                seg_idx += 1
-                yield Segment(seek=seg["seek"], id=seg_idx, text=seg["text"], start=round(seg["start"], 3),
-                              end=round(seg["end"], 3), tokens=seg["tokens"],
-                              words=(None if not options.word_timestamps else [Word(**w) for w in seg["words"]]),
-                              avg_logprob=seg["avg_logprob"], no_speech_prob=seg["no_speech_prob"],
-                              compression_ratio=seg["compression_ratio"], temperature=options.temperatures[0])
+        yield from emit(results)
         self.last_speech_timestamp = 0.0
 
 

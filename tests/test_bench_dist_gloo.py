@@ -1,0 +1,145 @@
+"""Dry run of bench.py's N > 1 control flow on CPU: two processes over `gloo`, a scripted backend instead of the
+HIP engine.  Everything between the collectives is the real code path of the 8-GPU run the driver launches — rank /
+world from the environment, weight-blob pack on rank 0 + broadcast + the arguments fw_model_create_from_blob_dev
+would receive, the worker pool, per-step result gather, the max-over-ranks timing, the cap case, the sharded
+1 h recording (BatchedInferencePipeline.transcribe(shard=True)), one JSON line from rank 0 — so the first real
+multi-GPU run cannot die on plumbing.  (The engine itself is covered by the -m gpu tests.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, struct, sys, threading
+import numpy as np
+sys.path.insert(0, os.environ["FW_ROOT"])
+import bench
+
+
+class Result:
+    def __init__(self, ids, score, nsp):
+        self.sequences_ids, self.scores, self.no_speech_prob = [ids], [score], nsp
+
+
+class FakeEnc:
+    def __init__(self, keys):
+        self.keys = keys
+
+
+class FakeBackend:
+    """what bench.py and the batched pipeline touch of backend.Whisper; ids are a pure function of the PCM"""
+    def __init__(self, cfg, workers, blob_dev):
+        self.config, self.is_multilingual, self.n_mels = cfg, cfg.is_multilingual, cfg.n_mels
+        self.device, self.device_index, self.inter_threads = "cpu", [0], workers
+        self.blob_dev = blob_dev
+        self.lock = threading.Lock()
+        self.calls = {"encode": 0, "generate": 0, "chunks": 0}
+
+    def _keys(self, chunks):
+        return [int(abs(float(np.asarray(c[:64]).sum())) * 1e4) % 9973 for c in chunks]
+
+    def stage_pcm(self, chunks, replica=0):
+        return {"chunks": chunks}
+
+    def free_staged(self, staged):
+        pass
+
+    def encode_pcm_staged(self, staged):
+        return self.encode_pcm(staged["chunks"])
+
+    def encode_pcm(self, chunks):
+        with self.lock:
+            self.calls["encode"] += 1
+        return FakeEnc(self._keys(chunks))
+
+    def generate(self, enc, prompts, *, max_length=448, **kw):
+        with self.lock:
+            self.calls["generate"] += 1
+            self.calls["chunks"] += len(enc.keys)
+        out = []
+        for k, p in zip(enc.keys, prompts):
+            n = max_length - len(p)
+            out.append(Result([(k + 3 * i) % 300 + 10 for i in range(n)], -0.001 * (k % 500) - 0.01, (k % 10) / 20.0))
+        return out
+
+    def decode_stats(self):
+        c = self.calls
+        return {"runs": c["generate"], "requests": c["generate"], "chunks": c["chunks"], "max_run_chunks": 4,
+                "decode_batch": 4 * self.inter_threads}
+
+    def synchronize(self):
+        pass
+
+    def profile(self, enable=True, replica=0):
+        pass
+
+    def profile_report(self, replica=0):
+        return {"dec_cross_attn": dict(ms=2.0, launches=4, flops=0.0, bytes=8e9),
+                "enc_gemm": dict(ms=1.0, launches=2, flops=1e12, bytes=0.0)}
+
+
+def factory(args, cfg, rank, world, local_rank):
+    """bench.build_backend with the engine replaced: the blob is really packed (host-side packer of libfwamd.so) and
+    really broadcast; every rank checks what it would hand to fw_model_create_from_blob_dev"""
+    from faster_whisper_amd import pack_blob, synthetic_weights
+    from faster_whisper_amd.sharding import broadcast_blob
+    blob = None
+    if rank == 0:
+        blob = pack_blob(cfg, synthetic_weights(cfg, seed=1234), 0)
+    t = broadcast_blob(blob, rank, local_rank)
+    raw = t.numpy()
+    assert raw[:8].tobytes() == b"FWAMDBL1", raw[:8].tobytes()
+    total = struct.unpack_from("<q", raw.tobytes()[:32], 16)[0]
+    assert total == raw.shape[0], (total, raw.shape)
+    assert t.data_ptr() != 0 and t.numel() == total
+    return FakeBackend(cfg, args.workers, (t.data_ptr(), t.numel())), None
+
+
+out = bench.main(["--gpus", os.environ["WORLD_SIZE"], "--model", "micro", "--batch", "4", "--beam", "5", "--steps", "6",
+                  "--warmup", "1", "--workers", "2", "--new-tokens", "12", "--pipeline-chunks", "11",
+                  "--no-cpu-baseline"], backend_factory=factory, dist_backend="gloo")
+if int(os.environ["RANK"]) != 0:
+    print("RANK_DONE", flush=True)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FW_ROOT=ROOT, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=280) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    assert "RANK_DONE" in outs[1][0]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][0]          # ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["global_batch"] == 8 and j["config"]["workers_per_gpu"] == 2
+    assert j["cap_case"]["new_tokens"] == 224 and j["cap_case"]["value"] > 0
+    sh = j["sharded_recording"]
+    assert "error" not in sh, sh
+    # rank 0 yielded every chunk of the recording, in order: one segment per 30 s chunk
+    assert sh["segments"] == 11 and sh["scaling"] == "strong" and sh["n_gpus"] == 2 and sh["tokens"] == 11 * 12
+    assert j["roofline"]["kernel"] == "dec_cross_attn" and j["roofline"]["bound"] == "hbm"
+    assert "cpu_baseline" not in j and "pipeline" not in j      # N = 1 only
