@@ -659,6 +659,7 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   DecodeGroup& grp = dm->grp;
   std::unique_lock<std::mutex> lk(grp.mu);
   grp.queue.push_back(&req);
+  grp.last_arrival = std::chrono::steady_clock::now();
   while (!req.done) {
     if (grp.leader_active) {
       grp.cv.wait(lk);
@@ -670,12 +671,14 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     grp.leader_active = true;
     const int cap = std::max(dm->decode_batch, dm->max_batch);
     if (cap > dm->max_batch && !grp.queue.front()->sampling) {
-      const auto t0 = std::chrono::steady_clock::now();
+      // FWAMD_GROUP_FILL (experiment): fraction of the workspace to wait for, default one half
+      static const double fill = [] { const char* e = getenv("FWAMD_GROUP_FILL"); return e ? atof(e) : 0.5; }();
       for (;;) {
         int queued = 0;
         for (const GenRequest* r : grp.queue) queued += r->B;
-        if (queued * 2 >= cap || grp.encoding.load() <= 0) break;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(150)) break;
+        if ((double)queued >= fill * cap || queued + dm->max_batch > cap || grp.encoding.load() <= 0) break;
+        // requests keep arriving one encoder pass apart: give up 120 ms after the last arrival
+        if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(120)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
       }
     }

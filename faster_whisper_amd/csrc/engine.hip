@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -1178,8 +1179,15 @@ namespace {
 // for it instead of starting with a nearly empty workspace)
 struct EncodingMark {
   fw::DecodeGroup& g;
-  explicit EncodingMark(fw::Model* m) : g(fw::decoder_of(m)->grp) { g.encoding.fetch_add(1); }
+  bool serial;
+  explicit EncodingMark(fw::Model* m) : g(fw::decoder_of(m)->grp) {
+    g.encoding.fetch_add(1);
+    static const bool ser = [] { const char* e = getenv("FWAMD_ENC_SERIAL"); return e && e[0] == '1'; }();
+    serial = ser;
+    if (serial) g.enc_mu.lock();
+  }
   ~EncodingMark() {
+    if (serial) g.enc_mu.unlock();
     g.encoding.fetch_sub(1);
     g.cv.notify_all();
   }
