@@ -35,10 +35,15 @@ class StorageView:
     """N-d tensor handle: either a borrowed host numpy array (from_array) or a
     device-resident encoder output owned by the engine."""
 
-    def __init__(self, array: Optional[np.ndarray] = None, handle=None, owner=None, shape=None):
+    def __init__(self, array: Optional[np.ndarray] = None, handle=None, owner=None, shape=None, parts=None):
         self._array = array
         self._handle = handle
         self._owner = owner  # the _Replica that produced the handle
+        # an encoder output of more chunks than the engine's max_batch is a list of device tensors (CTranslate2
+        # takes any batch size; the engine's workspaces are sized once)
+        self._parts = parts
+        if parts:
+            shape = (sum(p._shape[0] for p in parts),) + tuple(parts[0]._shape[1:])
         self._shape = tuple(shape) if shape is not None else (tuple(array.shape) if array is not None else ())
 
     @classmethod
@@ -54,7 +59,7 @@ class StorageView:
 
     @property
     def device(self) -> str:
-        return "cpu" if self._handle is None else "cuda"
+        return "cpu" if self._handle is None and not self._parts else "cuda"
 
     @property
     def dtype(self):
@@ -62,6 +67,8 @@ class StorageView:
 
     def to_numpy(self) -> np.ndarray:
         """float32 copy on the host (for device tensors: the to_cpu path)."""
+        if self._parts:
+            return np.concatenate([p.to_numpy() for p in self._parts], axis=0)
         if self._handle is None:
             return np.asarray(self._array)
         out = np.empty(self._shape, dtype=np.float32)
@@ -234,6 +241,7 @@ class Whisper:
         else:
             cfg, weights = load_model_dir(model_path)
         self._cfg = cfg
+        self._max_batch = int(max_batch_size)
         idx = [device_index] if isinstance(device_index, int) else list(device_index)
         self._device_index = idx
         self._lib = _lib.load()
@@ -318,7 +326,7 @@ class Whisper:
 
     def _as_encoded(self, features: StorageView) -> StorageView:
         """generate/detect_language/align accept an encoder output or raw features (like CTranslate2)."""
-        if features._handle is not None:
+        if features._handle is not None or features._parts:
             return features
         a = np.asarray(features._array)
         if a.ndim == 3 and a.shape[1] == self._cfg.n_audio_ctx and a.shape[2] == self._cfg.d_model:
@@ -342,6 +350,10 @@ class Whisper:
                 f"Invalid input features shape: expected an input with shape (B, {self._cfg.n_mels}, 3000), "
                 f"but got an input with shape {tuple(a.shape)} instead")
         a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape[0] > self._max_batch:
+            out = StorageView(parts=[self.encode(StorageView.from_array(a[i:i + self._max_batch]))
+                                     for i in range(0, a.shape[0], self._max_batch)])
+            return StorageView.from_array(out.to_numpy()) if to_cpu else out
         rep = self._replica_for(None)
         h = C.c_void_p()
         _lib.check(self._lib.fw_encode(rep.handle, _lib.ptr(a), a.shape[0], C.byref(h)))
@@ -352,6 +364,9 @@ class Whisper:
 
     def encode_pcm(self, chunks: Sequence[np.ndarray]) -> StorageView:
         """Fused resident path (not in CTranslate2): ragged PCM -> log-mel -> encoder on the GPU."""
+        if len(chunks) > self._max_batch:
+            return StorageView(parts=[self.encode_pcm(chunks[i:i + self._max_batch])
+                                      for i in range(0, len(chunks), self._max_batch)])
         rep = self._replica_for(None)
         pcm, offs = _ragged(chunks, np.float32)
         h = C.c_void_p()
@@ -415,6 +430,19 @@ class Whisper:
             raise ValueError(f"got {len(prompts)} prompts for a batch of {B}")
         if any(len(p) == 0 for p in prompts):
             raise ValueError("prompts must not be empty")
+        if enc._parts:
+            kw = dict(beam_size=beam_size, patience=patience, num_hypotheses=num_hypotheses,
+                      length_penalty=length_penalty, repetition_penalty=repetition_penalty,
+                      no_repeat_ngram_size=no_repeat_ngram_size, max_length=max_length, return_scores=return_scores,
+                      return_no_speech_prob=return_no_speech_prob,
+                      max_initial_timestamp_index=max_initial_timestamp_index, suppress_blank=suppress_blank,
+                      suppress_tokens=suppress_tokens, sampling_topk=sampling_topk,
+                      sampling_temperature=sampling_temperature, min_new_tokens=min_new_tokens, seed=seed)
+            out, b0 = [], 0
+            for part in enc._parts:
+                out.extend(self.generate(part, prompts[b0:b0 + part._shape[0]], **kw))
+                b0 += part._shape[0]
+            return out
         flat, offs = _ragged([np.asarray(p, dtype=np.int32) for p in prompts], np.int32, np.int32)
         o = _lib.FwGenOpts()
         o.beam_size, o.patience, o.num_hypotheses = int(beam_size), float(patience), int(num_hypotheses)
@@ -453,6 +481,8 @@ class Whisper:
         if not self.is_multilingual:
             raise RuntimeError("detect_language can only be called on multilingual models")
         enc = self._as_encoded(features if isinstance(features, StorageView) else StorageView.from_array(features))
+        if enc._parts:
+            return [row for part in enc._parts for row in self.detect_language(part)]
         B, nl = enc._shape[0], self._cfg.n_langs
         ids = np.zeros((B, nl), dtype=np.int32)
         probs = np.zeros((B, nl), dtype=np.float32)
@@ -473,6 +503,14 @@ class Whisper:
         nf = np.asarray([num_frames] * B if isinstance(num_frames, int) else list(num_frames), dtype=np.int32)
         if nf.shape[0] != B:
             raise ValueError("num_frames must be an int or have one entry per batch item")
+        if enc._parts:
+            out, b0 = [], 0
+            for part in enc._parts:
+                n = part._shape[0]
+                out.extend(self.align(part, start_sequence, text_tokens[b0:b0 + n], nf[b0:b0 + n].tolist(),
+                                      median_filter_width=median_filter_width))
+                b0 += n
+            return out
         start = np.asarray(list(start_sequence), dtype=np.int32)
         flat, offs = _ragged([np.asarray(t, dtype=np.int32) for t in text_tokens], np.int32, np.int32)
         max_pairs = int(max((len(t) for t in text_tokens), default=0)) + self._cfg.n_audio_ctx + 2

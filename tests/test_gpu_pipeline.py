@@ -129,3 +129,30 @@ def test_worker_replicas_share_weights(wm):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert out[0] == out[1] and len(out[0][0]) == 16
+
+
+def test_batches_larger_than_the_engine_workspace(wm):
+    """CTranslate2 accepts any batch size; the engine's workspaces hold max_batch_size chunks, so the front splits a
+    larger batch into sub-batches (encode, generate, detect_language, align) and concatenates the results"""
+    from faster_whisper_amd import Whisper
+    cfg, w, _ = wm
+    model = Whisper("synthetic:micro", device="cuda", files={"config": cfg, "weights": w}, max_batch_size=2,
+                    max_beam_size=5)
+    chunks = [bench_audio(480000 if i % 2 else 300000, seed=20 + i) for i in range(5)]
+    prompt = [cfg.sot, cfg.lang_begin, cfg.transcribe, cfg.no_timestamps]
+    enc = model.encode_pcm(chunks)
+    assert enc.shape == [5, 1500, cfg.d_model] and enc.to_numpy().shape == (5, 1500, cfg.d_model)
+    kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True, return_no_speech_prob=True)
+    got = model.generate(enc, [prompt] * 5, **kw)
+    lang = model.detect_language(enc)
+    al = model.align(enc, cfg.sot_sequence, [[11, 12, 13]] * 5, [3000, 1800, 3000, 1800, 3000])
+    assert len(got) == len(lang) == len(al) == 5
+    for i in range(5):
+        e1 = model.encode_pcm(chunks[i:i + 1])
+        one = model.generate(e1, [prompt], **kw)[0]
+        assert got[i].sequences_ids == one.sequences_ids and got[i].scores == one.scores
+        assert lang[i] == model.detect_language(e1)[0]
+    feats = model.log_mel(chunks)
+    assert model.encode(feats).shape == [5, 1500, cfg.d_model]
+    with pytest.raises(ValueError):
+        model.generate(enc, [prompt] * 5, beam_size=6)          # beam_size is bounded by max_beam_size
