@@ -107,7 +107,7 @@ struct DecodeGroup {
   bool leader_active = false;
   std::atomic<int> encoding{0};   // member encodes in flight: requests that are about to arrive
   std::chrono::steady_clock::time_point last_arrival{};   // when the newest request was queued
-  std::mutex enc_mu;              // experiment (FWAMD_ENC_SERIAL=1): one encoder pass at a time per device
+  std::mutex enc_mu;              // one encoder pass at a time per device
   // statistics (fw_model_decode_stats): decode runs, fw_generate calls served, chunks decoded, largest run
   std::atomic<int64_t> n_runs{0}, n_requests{0}, n_chunks{0};
   std::atomic<int> max_run_chunks{0};

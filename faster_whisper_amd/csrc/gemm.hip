@@ -48,7 +48,7 @@
 #define GB_N 256
 #define GB_UNIT_BYTES (128 * 128)          // one staging unit: 128 rows x 128 B
 #define GB_SLOT_BYTES (4 * GB_UNIT_BYTES)  // one K tile: A0, A1, B0, B1
-#define GB_LDS_BYTES (2 * GB_SLOT_BYTES)   // two K tiles in the ring
+#define GB_LDS_BYTES (8 * 128 * 144)       // the ring (2 K tiles = 128 KB); the epilogue stages 8 x 18 KB through it
 
 typedef int intx16 __attribute__((ext_vector_type(16)));
 
@@ -209,20 +209,28 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
 
   // ---------------------------------- epilogue ----------------------------------
   const float* sa = I8 ? p.a_scale + (size_t)z * p.as_bstride : nullptr;
-  if (!TRANS) {
+  if (!TRANS && p.head_rows == 0) {
+    // Row-major output: the accumulator layout gives a lane 4 consecutive n of ONE row, so direct stores would be
+    // 32 eight-byte stores per lane into 32 different cache lines per instruction — store-issue bound, and with one
+    // workgroup per CU nothing hides that tail.  Instead the wave's 128 x 64 sub-tile goes through its own 18 KB
+    // of the (now idle) LDS ring and leaves as whole 128-byte row segments, 16 B per lane; bias and activation are
+    // applied on the way in, the residual (read with the same coalesced pattern) on the way out.
+    constexpr int EP_STRIDE = 144;                       // bytes per staged row: 128 + 16 (keeps 16-B alignment)
+    char* ep = smem_raw + wave * (128 * EP_STRIDE);
     half_t* Cb = p.C + (size_t)z * p.c_bstride;
     const half_t* Rb = p.res ? p.res + (size_t)z * p.r_bstride : nullptr;
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;     // this wave's sub-tile
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 128 + mi * 32 + l31;
-        if (m >= p.M) continue;
-        const float sam = I8 ? sa[m] : 1.f;
+        const int r = mi * 32 + l31;
+        int mc = mw + r; if (mc > p.M - 1) mc = p.M - 1;
+        const float sam = I8 ? sa[mc] : 1.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
-          if (n >= p.N) continue;
+          const int c = ni * 32 + 8 * g + 4 * hi;
+          int n = nw + c; if (n > p.N - 4) n = p.N - 4;  // clamped columns are never stored
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -236,26 +244,63 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
           }
-          if (Rb) {
-            const half4_t rv = *reinterpret_cast<const half4_t*>(Rb + (size_t)m * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          }
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          half_t* dst;
-          if (p.head_rows > 0) {
-            // cross-attention K, MFMA-fragment-major per (chunk, head): a 32-key group is 4 runs of 64 lanes x 16 B,
-            // run q = 2*sub + s, lane = 16*g + j  <->  key 32*gi + 8*(j>>2) + 4*sub + (j&3), dims 32*s + 8*g + [0,8)
-            const int c = n & 63, r = m & 31;
-            const int run = (m >> 5) * 4 + 2 * ((r >> 2) & 1) + (c >> 5);
-            const int ln = ((c >> 3) & 3) * 16 + (((r >> 3) << 2) | (r & 3));
-            dst = Cb + (size_t)(n >> 6) * p.head_rows * 64 + ((size_t)run * 64 + ln) * 8 + (c & 7);
-          } else {
-            dst = Cb + (size_t)m * p.ldc + n;
+          *reinterpret_cast<half4_t*>(ep + r * EP_STRIDE + c * 2) = o;
+        }
+      }
+    // (a wave's LDS operations execute in order: its reads below see its writes above)
+    const int rr = lane >> 3, cc = (lane & 7) * 8;       // 8 lanes per row segment, 8 halves each
+    const bool vec_ok = (p.ldc % 8 == 0) && (p.c_bstride % 8 == 0) && (!Rb || ((p.ldr % 8 == 0) && (p.r_bstride % 8 == 0)));
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int r = j * 8 + rr;
+      const int m = mw + r, n = nw + cc;
+      half8_t o = *reinterpret_cast<const half8_t*>(ep + r * EP_STRIDE + cc * 2);
+      if (m >= p.M || n >= p.N) continue;
+      if (vec_ok && n + 8 <= p.N) {
+        if (Rb) {
+          const half8_t rv = *reinterpret_cast<const half8_t*>(Rb + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+        }
+        *reinterpret_cast<half8_t*>(Cb + (size_t)m * p.ldc + n) = o;
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float v = (float)o[e];
+          if (Rb) v += (float)Rb[(size_t)m * p.ldr + n + e];
+          Cb[(size_t)m * p.ldc + n + e] = (half_t)v;
+        }
+      }
+    }
+  } else if (!TRANS) {
+    // cross-attention K, MFMA-fragment-major per (chunk, head): a 32-key group is 4 runs of 64 lanes x 16 B,
+    // run q = 2*sub + s, lane = 16*g + j  <->  key 32*gi + 8*(j>>2) + 4*sub + (j&3), dims 32*s + 8*g + [0,8)
+    half_t* Cb = p.C + (size_t)z * p.c_bstride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 128 + mi * 32 + l31;
+        if (m >= p.M) continue;
+        const float sam = I8 ? sa[m] : 1.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
+          if (n >= p.N) continue;
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
+            if (p.bias) v += (float)p.bias[n + e];
+            if (p.act == 1) v = gelu_erf(v);
+            o[e] = (half_t)v;
           }
-          *reinterpret_cast<half4_t*>(dst) = o;
+          const int c = n & 63, r = m & 31;
+          const int run = (m >> 5) * 4 + 2 * ((r >> 2) & 1) + (c >> 5);
+          const int ln = ((c >> 3) & 3) * 16 + (((r >> 3) << 2) | (r & 3));
+          *reinterpret_cast<half4_t*>(Cb + (size_t)(n >> 6) * p.head_rows * 64 + ((size_t)run * 64 + ln) * 8 + (c & 7)) = o;
         }
       }
   } else {

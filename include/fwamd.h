@@ -274,6 +274,11 @@ int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const fl
 /* the vocabulary projection of a decode step: x [R][d] raw residual rows -> float32 logits [R][n_vocab] (final
  * LayerNorm folded in fp16 mode, applied by the row quantiser in int8_float16 mode), with the model's own weights */
 int32_t fw_test_dec_logits(fw_model* m, const float* x, int32_t R, float* out);
+/* measurement hook (profiles/gemm_bench.py): average milliseconds of one launch of the "many rows" GEMM
+ * C[batch][M][N] = A[batch][M][K] W[N][K]^T on device-resident pseudo-random operands (fp16, or int8 on an
+ * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
+int32_t fw_bench_gemm(fw_model* m, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
+                      int32_t trans, int32_t iters, float* ms_out);
 int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const float* b,
                           int32_t rows, int32_t d, float* out);
 int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,

@@ -179,7 +179,7 @@ def test_generate_int8(setup, beam):
             assert g.sequences_ids[0][:n] == r.sequences_ids[0][:n]
         # score of the engine's own ids under the oracle always within 5e-3 (a flipped int8 code is visible);
         # different ids only when the two hypotheses are tied within 4e-2 under the oracle's scoring
-        check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, tol=5e-3, gap=4e-2,
+        check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, tol=5e-3, gap=4e-2, search=beam > 1,
                          what=f"[{cfg.name}] int8 beam={beam} chunk {b}")
         assert abs(g.no_speech_prob - r.no_speech_prob) < 2e-3
 

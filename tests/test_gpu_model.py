@@ -138,7 +138,8 @@ def test_generate_eot_and_early_finish(setup):
         ref = oracle.generate(enc_np, [prompt] * 3, **kw)
         for b, (g, r) in enumerate(zip(got, ref)):
             assert len(g.sequences_ids[0]) <= 3
-            check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, what=f"[{cfg.name}] budget-3 beam={beam} chunk {b}")
+            check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, search=beam > 1,
+                             what=f"[{cfg.name}] budget-3 beam={beam} chunk {b}")
     # <eot> allowed from the first step and made attractive by suppressing (almost) everything else: hypotheses
     # finish early, the finished list fills up and the run stops before the budget
     keep = {cfg.eot, 20, 21, 22}
@@ -149,7 +150,8 @@ def test_generate_eot_and_early_finish(setup):
         ref = oracle.generate(enc_np, [prompt] * 3, **kw)
         for b, (g, r) in enumerate(zip(got, ref)):
             assert all(t in keep for t in g.sequences_ids[0])
-            check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, what=f"[{cfg.name}] eot-heavy beam={beam} chunk {b}")
+            check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, search=beam > 1,
+                             what=f"[{cfg.name}] eot-heavy beam={beam} chunk {b}")
 
 
 def test_generate_sampling(setup):
