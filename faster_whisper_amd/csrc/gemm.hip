@@ -48,7 +48,7 @@
 #define GB_N 256
 #define GB_UNIT_BYTES (128 * 128)          // one staging unit: 128 rows x 128 B
 #define GB_SLOT_BYTES (4 * GB_UNIT_BYTES)  // one K tile: A0, A1, B0, B1
-#define GB_LDS_BYTES (8 * 128 * 144)       // the ring (2 K tiles = 128 KB); the epilogue stages 8 x 18 KB through it
+#define GB_LDS_BYTES (8 * 64 * 272)        // the ring (2 K tiles = 128 KB); the epilogue stages 8 x 17 KB through it
 
 typedef int intx16 __attribute__((ext_vector_type(16)));
 
@@ -212,65 +212,73 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   if (!TRANS && p.head_rows == 0) {
     // Row-major output: the accumulator layout gives a lane 4 consecutive n of ONE row, so direct stores would be
     // 32 eight-byte stores per lane into 32 different cache lines per instruction — store-issue bound, and with one
-    // workgroup per CU nothing hides that tail.  Instead the wave's 128 x 64 sub-tile goes through its own 18 KB
-    // of the (now idle) LDS ring and leaves as whole 128-byte row segments, 16 B per lane; bias and activation are
-    // applied on the way in, the residual (read with the same coalesced pattern) on the way out.
-    constexpr int EP_STRIDE = 144;                       // bytes per staged row: 128 + 16 (keeps 16-B alignment)
-    char* ep = smem_raw + wave * (128 * EP_STRIDE);
+    // workgroup per CU nothing hides that tail.  Instead the wave's 128 x 64 sub-tile goes through its own 17 KB
+    // of the (now idle) LDS ring, in two halves of 64 rows, as float32 — bias and activation applied on the way
+    // in — and leaves as whole 128-byte row segments, 16 B per lane, the residual (read with the same coalesced
+    // pattern) added BEFORE the one rounding to fp16: y = fp16(act(acc + bias) + res), as the oracle states it.
+    constexpr int EP_STRIDE = 272;                       // bytes per staged row: 64 floats + 16 (16-B aligned)
+    char* ep = smem_raw + wave * (64 * EP_STRIDE);
     half_t* Cb = p.C + (size_t)z * p.c_bstride;
     const half_t* Rb = p.res ? p.res + (size_t)z * p.r_bstride : nullptr;
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;     // this wave's sub-tile
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int r = mi * 32 + l31;
-        int mc = mw + r; if (mc > p.M - 1) mc = p.M - 1;
-        const float sam = I8 ? sa[mc] : 1.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = ni * 32 + 8 * g + 4 * hi;
-          int n = nw + c; if (n > p.N - 4) n = p.N - 4;  // clamped columns are never stored
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
-          if (p.bias) {
-            const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-          }
-          if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          }
-          half4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          *reinterpret_cast<half4_t*>(ep + r * EP_STRIDE + c * 2) = o;
-        }
-      }
-    // (a wave's LDS operations execute in order: its reads below see its writes above)
-    const int rr = lane >> 3, cc = (lane & 7) * 8;       // 8 lanes per row segment, 8 halves each
+    const int rr = lane >> 3, cc = (lane & 7) * 8;       // store pass: 8 lanes per row segment, 8 columns each
     const bool vec_ok = (p.ldc % 8 == 0) && (p.c_bstride % 8 == 0) && (!Rb || ((p.ldr % 8 == 0) && (p.r_bstride % 8 == 0)));
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-      const int r = j * 8 + rr;
-      const int m = mw + r, n = nw + cc;
-      half8_t o = *reinterpret_cast<const half8_t*>(ep + r * EP_STRIDE + cc * 2);
-      if (m >= p.M || n >= p.N) continue;
-      if (vec_ok && n + 8 <= p.N) {
-        if (Rb) {
-          const half8_t rv = *reinterpret_cast<const half8_t*>(Rb + (size_t)m * p.ldr + n);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+          const int mi = half * 2 + mh;
+          const int r = mh * 32 + l31;                   // row inside the staged half
+          int mc = mw + half * 64 + r; if (mc > p.M - 1) mc = p.M - 1;
+          const float sam = I8 ? sa[mc] : 1.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = ni * 32 + 8 * g + 4 * hi;
+            int n = nw + c; if (n > p.N - 4) n = p.N - 4;  // clamped columns are never stored
+            floatx4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
+            if (p.bias) {
+              const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+            }
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            *reinterpret_cast<floatx4*>(ep + r * EP_STRIDE + c * 4) = v;
+          }
         }
-        *reinterpret_cast<half8_t*>(Cb + (size_t)m * p.ldc + n) = o;
-      } else {
-        for (int e = 0; e < 8 && n + e < p.N; ++e) {
-          float v = (float)o[e];
-          if (Rb) v += (float)Rb[(size_t)m * p.ldr + n + e];
-          Cb[(size_t)m * p.ldc + n + e] = (half_t)v;
+      // (a wave's LDS operations execute in order: its reads below see its writes above, and the next half's
+      //  writes come after these reads)
+#pragma unroll 4
+      for (int j = 0; j < 8; ++j) {
+        const int r = j * 8 + rr;
+        const int m = mw + half * 64 + r, n = nw + cc;
+        const floatx4 v0 = *reinterpret_cast<const floatx4*>(ep + r * EP_STRIDE + cc * 4);
+        const floatx4 v1 = *reinterpret_cast<const floatx4*>(ep + r * EP_STRIDE + cc * 4 + 16);
+        if (m >= p.M || n >= p.N) continue;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (vec_ok && n + 8 <= p.N) {
+          if (Rb) {
+            const half8_t rv = *reinterpret_cast<const half8_t*>(Rb + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+          }
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+          *reinterpret_cast<half8_t*>(Cb + (size_t)m * p.ldc + n) = o;
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) {
+            float t = v[e];
+            if (Rb) t += (float)Rb[(size_t)m * p.ldr + n + e];
+            Cb[(size_t)m * p.ldc + n + e] = (half_t)t;
+          }
         }
       }
     }

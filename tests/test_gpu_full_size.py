@@ -6,7 +6,7 @@ The engine always runs the whole batch of 16; the CPU oracle (fp16 storage emula
 on a 2-chunk subset (first chunk, and one in the last row tile) because a large-v3 beam step costs about a second
 of CPU.  What is compared, per configuration:
   * encoder output of one chunk (relative max / rms error);
-  * >= 8 teacher-forced greedy steps: cumulative log-prob of the engine's own ids under the oracle, 2e-3;
+  * >= 8 teacher-forced greedy steps: log-prob of the engine's own ids under the oracle, 1e-3 per token;
   * beam 5: score of the engine's hypothesis under the oracle within 1e-3, ids identical or tied (conftest.
     check_hypothesis), no-speech probability 1e-3;
   * detect_language probabilities 4e-3; align: token probabilities 3e-3, word-boundary frames <= 2
@@ -46,15 +46,15 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=6):
     from faster_whisper_amd.backend import StorageView, language_token_strings
     from oracle.whisper import OracleWhisper
     i8 = compute_type == "int8_float16"
-    # Tolerances.  fp16: the north-star 1e-3 on beam scores; 2e-3 on the cumulative log-prob of 8+ teacher-forced
-    # steps; 4e-3 / 3e-3 on language / token PROBABILITIES (a probability near 0.5 moves by a quarter of the logit
+    # Tolerances.  fp16: the north-star 1e-3 on beam scores and on the per-token average of 8+ teacher-forced
+    # steps' log-probs; 4e-3 / 3e-3 on language / token PROBABILITIES (a probability near 0.5 moves by a quarter of the logit
     # error, and 32 decoder layers of fp16 rounding put ~1e-2 on a logit: measured 2.3e-3 / 1.6e-3; the 2-layer
     # distil decoder stays below 1e-3).  int8_float16: the engine and the oracle quantise activations that differ
     # by fp16 rounding, a flipped int8 code is 1/127 of a row's range and 2 x 32 quantised blocks accumulate them:
     # measured 1.3e-2 rms on the encoder output, 2.8e-2 on an 8-step log-prob, 2e-2 on a beam score, 2e-2 on
     # probabilities — every single int8 GEMM is bit-exact against the integer reference (tests/test_gpu_int8.py).
-    tol = dict(tf=4e-2, beam=3e-2, gap=6e-2, nsp=1e-2, lang=3e-2, align=3e-2, enc=(6e-2, 2e-2)) if i8 else \
-        dict(tf=2e-3, beam=1e-3, gap=2e-2, nsp=1e-3, lang=4e-3, align=3e-3, enc=(3e-2, 5e-3))
+    tol = dict(tf=1.5e-2, beam=3e-2, gap=6e-2, nsp=1e-2, lang=3e-2, align=3e-2, enc=(6e-2, 2e-2)) if i8 else \
+        dict(tf=1e-3, beam=1e-3, gap=2e-2, nsp=1e-3, lang=4e-3, align=3e-3, enc=(3e-2, 5e-3))
     fails = []
 
     def expect(cond, msg):
@@ -89,7 +89,8 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=6):
     for j, b in enumerate(SUBSET):
         sf = forced_score(oracle, sub[j], prompt, g1[b].sequences_ids[0], kw)
         print(f"{tag} chunk {b}: teacher-forced cum logprob over {tf_steps} steps {g1[b].scores[0]:.5f} vs {sf:.5f}")
-        expect(abs(g1[b].scores[0] - sf) < tol["tf"] * max(1.0, abs(sf)), f"teacher-forced chunk {b}: {g1[b].scores[0]} vs {sf}")
+        # per generated token: the north-star tolerance is on avg_logprob = cum / (len + 1) (transcribe.py:241-246)
+        expect(abs(g1[b].scores[0] - sf) / tf_steps < tol["tf"], f"teacher-forced chunk {b}: {g1[b].scores[0]} vs {sf}")
 
     # ---- beam 5 x 16 chunks = 80 rows (the bench geometry) ----
     kw = dict(beam_size=5, patience=1.0, length_penalty=1.0, max_length=len(prompt) + beam_steps, suppress_tokens=sup)
