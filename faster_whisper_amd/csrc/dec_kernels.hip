@@ -13,7 +13,6 @@
 #include "common.h"
 #include "dec_kernels.h"
 #include <stdlib.h>
-#include <string.h>
 
 // ------------------------------------------------------------------------------------
 // K12: token + learned-position embedding  x[r] = E[tok[r]] + pos[p]
@@ -1077,24 +1076,11 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act) {
   if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
-  int waves = K >= 2560 ? 8 : 4;   // keeps a wave's share at <= 20 k-steps = 2 chunks of loads
-  int rt = 2, nt = 2;
-  // experiment (merged decode runs, R > 80): FWAMD_FRAG=rt,nt,waves
-  static const int ex[3] = {[] { const char* e = getenv("FWAMD_FRAG"); return e ? atoi(e) : 0; }(),
-                            [] { const char* e = getenv("FWAMD_FRAG"); return e && strchr(e, ',') ? atoi(strchr(e, ',') + 1) : 0; }(),
-                            [] { const char* e = getenv("FWAMD_FRAG"); const char* c = e ? strchr(e, ',') : nullptr; c = c ? strchr(c + 1, ',') : nullptr; return c ? atoi(c + 1) : 0; }()};
-  if (R > 80 && ex[0]) { rt = ex[0]; nt = ex[1] ? ex[1] : 2; if (ex[2] == 4 || ex[2] == 8) waves = ex[2]; }
-  if (N % (16 * nt)) nt = 2;
-#define FG(RT_, NT_)                                                                                          \
-  do {                                                                                                        \
-    if (s1) frag_go<true, RT_, NT_>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act); \
-    else frag_go<false, RT_, NT_>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);  \
-  } while (0)
-  if (rt == 4 && nt == 2) FG(4, 2);
-  else if (rt == 2 && nt == 4) FG(2, 4);
-  else if (rt == 4 && nt == 4) FG(4, 4);
-  else FG(2, 2);
-#undef FG
+  const int waves = K >= 2560 ? 8 : 4;   // keeps a wave's share at <= 20 k-steps = 2 chunks of loads
+  // 2 x 2 tiles also for the merged runs (R up to 640): 4 x 2, 2 x 4, 4 x 4 tiles and 8 waves for every K measured
+  // 2 135 / 2 200 / 1 937 / 2 264x against 2 304x (round 2, profiles/README.md)
+  if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
   return 0;
 }
 

@@ -1,11 +1,61 @@
-// K5 — LayerNorm (eps 1e-5, affine), fp16 in/out, fp32 statistics; plus dtype casts.
-// One 64-lane wave per row, the whole row lives in registers (d <= 1280 -> <= 10
-// half2 per lane), mean and variance are two shuffle reductions (no LDS, no
-// second HBM pass).  HBM-bound: 2*d*2 bytes per row.
+// K5 — LayerNorm (eps 1e-5, affine), fp16 in/out, fp32 statistics; the int8 row quantiser; dtype casts.
+// One 64-lane wave per row, the whole row lives in registers as 16-byte chunks (8 halves per lane per access:
+// scalar / half2 accesses run these HBM-bound kernels at less than half the rate), mean and variance are two
+// shuffle reductions (no LDS, no second HBM pass).  HBM-bound: 2*d*2 bytes per row (LayerNorm).
 #include "common.h"
 #include "kernels.h"
 
-#define LN_MAXV 10
+#define LN_MAXC 3    // 16-byte chunks per lane for a LayerNorm row: d <= 1536
+#define QR_MAXC 10   // ... for a plain row handed to the quantiser: d <= 5120
+
+// loads the row's chunks lane, lane + 64, ... into v[][8]; returns their sum
+template <int MAXC>
+static __device__ __forceinline__ float load_row(const half_t* xr, int nc, int lane, float (&v)[MAXC][8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nc) {
+      const half8_t h = *reinterpret_cast<const half8_t*>(xr + (size_t)c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)h[e]; s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  return s;
+}
+
+// y = LN(x) * g + b in place in v (rounded to fp16, as the tensor is stored); returns the row's absmax
+template <int MAXC>
+static __device__ __forceinline__ float normalise_row(float (&v)[MAXC][8], int nc, int lane, int d, float sum,
+                                                      const half_t* g, const half_t* b) {
+  const float mean = wave_sum(sum) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (i * 64 + lane < nc) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float a = v[i][e] - mean; q += a * a; }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nc) {
+      const half8_t gg = *reinterpret_cast<const half8_t*>(g + (size_t)c * 8);
+      const half8_t bb = *reinterpret_cast<const half8_t*>(b + (size_t)c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (float)(half_t)((v[i][e] - mean) * rstd * (float)gg[e] + (float)bb[e]);
+        amax = fmaxf(amax, fabsf(v[i][e]));
+      }
+    }
+  }
+  return amax;
+}
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ g,
                                                         const half_t* __restrict__ b, half_t* __restrict__ y,
@@ -13,47 +63,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int nv = d >> 7;  // half2 per lane
-  const half2_t* xr = reinterpret_cast<const half2_t*>(x + (size_t)row * d);
-  float v0[LN_MAXV], v1[LN_MAXV];
-  float s = 0.f;
+  const int nc = d >> 3;
+  float v[LN_MAXC][8];
+  const float s = load_row<LN_MAXC>(x + (size_t)row * d, nc, lane, v);
+  (void)normalise_row<LN_MAXC>(v, nc, lane, d, s, g, b);
+  half_t* yr = y + (size_t)row * d;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    if (i < nv) {
-      const half2_t h = xr[i * 64 + lane];
-      v0[i] = (float)h[0]; v1[i] = (float)h[1];
-      s += v0[i] + v1[i];
-    }
-  }
-  const float mean = wave_sum(s) / (float)d;
-  float q = 0.f;
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nc) {
+      half8_t o;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    if (i < nv) {
-      const float a = v0[i] - mean, c = v1[i] - mean;
-      q += a * a + c * c;
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-  const half2_t* gr = reinterpret_cast<const half2_t*>(g);
-  const half2_t* br = reinterpret_cast<const half2_t*>(b);
-  half2_t* yr = reinterpret_cast<half2_t*>(y + (size_t)row * d);
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    if (i < nv) {
-      const half2_t gg = gr[i * 64 + lane], bb = br[i * 64 + lane];
-      half2_t o;
-      o[0] = (half_t)((v0[i] - mean) * rstd * (float)gg[0] + (float)bb[0]);
-      o[1] = (half_t)((v1[i] - mean) * rstd * (float)gg[1] + (float)bb[1]);
-      yr[i * 64 + lane] = o;
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)v[i][e];
+      *reinterpret_cast<half8_t*>(yr + (size_t)c * 8) = o;
     }
   }
 }
 
 // K25 (activation side): per-row dynamic int8 quantisation, optionally fused with the LayerNorm that
 // produces the row.  scale[r] = absmax / 127 (de-quantisation factor), xq = rint(y / scale).
-// One wave per row; LayerNorm rows (d <= 1280) stay in registers, plain rows (d up to 5120) take a
-// second pass over L2-resident data.
+// One wave per row, the row stays in registers (LayerNorm rows d <= 1536, plain rows d <= 5120): one pass.
+// frag != 0: int8 MFMA-fragment-major destination (dec_gemm_frag_i8_kernel): element (row, k) lives at byte
+// ((row/16 * d/64 + k/64) * 64 + 16*((k/16)%4) + row%16) * 16 + k%16; a chunk of 8 consecutive k stays contiguous.
+template <int MAXC, bool LN>
+static __device__ __forceinline__ void quant_row(const half_t* xr, const half_t* g, const half_t* b, int8_t* xq,
+                                                 float* scale, int row, int d, int frag, int lane) {
+  const int nc = d >> 3;
+  float v[MAXC][8];
+  const float s = load_row<MAXC>(xr, nc, lane, v);
+  float amax = 0.f;
+  if (LN) {
+    amax = normalise_row<MAXC>(v, nc, lane, d, s, g, b);
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+  }
+  amax = wave_max(amax);
+  const float inv = amax > 0.f ? 127.0f / amax : 0.f;
+  if (lane == 0) scale[row] = amax > 0.f ? amax / 127.0f : 1.0f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nc) {
+      union { signed char q[8]; intx2 w; } o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.q[e] = (signed char)__float2int_rn(v[i][e] * inv);
+      const int k = c * 8;
+      const size_t off = frag ? ((size_t)((row >> 4) * (d >> 6) + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (row & 15)) * 16 + (k & 15)
+                              : (size_t)row * d + k;
+      *reinterpret_cast<intx2*>(xq + off) = o.w;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void quant_rows_kernel(const half_t* __restrict__ x, int64_t ldx,
                                                          const half_t* __restrict__ g, const half_t* __restrict__ b,
                                                          int8_t* __restrict__ xq, float* __restrict__ scale, int rows,
@@ -61,76 +125,10 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const half_t* __restric
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const half2_t* xr = reinterpret_cast<const half2_t*>(x + (size_t)row * ldx);
-  char2* qr = reinterpret_cast<char2*>(xq + (size_t)row * d);
-  // frag != 0: int8 MFMA-fragment-major destination (dec_gemm_frag_i8_kernel): element (row, k) lives at byte
-  // ((row/16 * d/64 + k/64) * 64 + 16*((k/16)%4) + row%16) * 16 + k%16; pair index p = k/2 stays contiguous
-  auto dst = [&](int p) -> char2* {
-    if (!frag) return qr + p;
-    const int k = 2 * p;
-    const size_t off = ((size_t)((row >> 4) * (d >> 6) + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (row & 15)) * 16 + (k & 15);
-    return reinterpret_cast<char2*>(xq + off);
-  };
-  const int nv = d >> 7;  // half2 per lane
-  if (g) {
-    float v0[LN_MAXV], v1[LN_MAXV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-      if (i < nv) {
-        const half2_t h = xr[i * 64 + lane];
-        v0[i] = (float)h[0]; v1[i] = (float)h[1];
-        s += v0[i] + v1[i];
-      }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-      if (i < nv) {
-        const float a = v0[i] - mean, c = v1[i] - mean;
-        q += a * a + c * c;
-      }
-    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-    const half2_t* gr = reinterpret_cast<const half2_t*>(g);
-    const half2_t* br = reinterpret_cast<const half2_t*>(b);
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-      if (i < nv) {
-        const half2_t gg = gr[i * 64 + lane], bb = br[i * 64 + lane];
-        // the LayerNorm output is an fp16 tensor in the reference pipeline: round before quantising
-        v0[i] = (float)(half_t)((v0[i] - mean) * rstd * (float)gg[0] + (float)bb[0]);
-        v1[i] = (float)(half_t)((v1[i] - mean) * rstd * (float)gg[1] + (float)bb[1]);
-        amax = fmaxf(amax, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
-      }
-    amax = wave_max(amax);
-    const float inv = amax > 0.f ? 127.0f / amax : 0.f;
-    if (lane == 0) scale[row] = amax > 0.f ? amax / 127.0f : 1.0f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-      if (i < nv) {
-        char2 o;
-        o.x = (signed char)__float2int_rn(v0[i] * inv);
-        o.y = (signed char)__float2int_rn(v1[i] * inv);
-        *dst(i * 64 + lane) = o;
-      }
-  } else {
-    float amax = 0.f;
-    for (int i = lane; i < d / 2; i += 64) {
-      const half2_t h = xr[i];
-      amax = fmaxf(amax, fmaxf(fabsf((float)h[0]), fabsf((float)h[1])));
-    }
-    amax = wave_max(amax);
-    const float inv = amax > 0.f ? 127.0f / amax : 0.f;
-    if (lane == 0) scale[row] = amax > 0.f ? amax / 127.0f : 1.0f;
-    for (int i = lane; i < d / 2; i += 64) {
-      const half2_t h = xr[i];
-      char2 o;
-      o.x = (signed char)__float2int_rn((float)h[0] * inv);
-      o.y = (signed char)__float2int_rn((float)h[1] * inv);
-      *dst(i) = o;
-    }
-  }
+  const half_t* xr = x + (size_t)row * ldx;
+  if (g) quant_row<LN_MAXC, true>(xr, g, b, xq, scale, row, d, frag, lane);
+  else if (d <= 8 * 64 * LN_MAXC) quant_row<LN_MAXC, false>(xr, g, b, xq, scale, row, d, frag, lane);
+  else quant_row<QR_MAXC, false>(xr, g, b, xq, scale, row, d, frag, lane);
 }
 
 __global__ void f32_to_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, int64_t n) {
