@@ -52,6 +52,12 @@
 
 typedef int intx16 __attribute__((ext_vector_type(16)));
 
+// profiles/ubench/gemm_timeline.hip compiles this file with GB_TL defined to stamp s_memtime at the segment
+// boundaries of one workgroup; in the product build the probes are empty
+#ifndef GB_TL
+#define GB_TL(slot)
+#endif
+
 // workgroup barrier that the compiler may not move LDS reads or DMA issues across (the raw builtin carries no fence;
 // the counted vmcnt protocol below is what orders the DMA ring, so no vmcnt(0) drain is wanted here)
 #define GB_BARRIER()                      \
@@ -177,32 +183,48 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
     const char* slot = smem_raw + (kt & 1) * GB_SLOT_BYTES;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
     // phase 1: A0 x B0
+    GB_TL(0);
     read_a(slot);
     read_b(slot + 2 * GB_UNIT_BYTES, fb0);
     if (n1) issue(3, kt + 1);
     seg_wait(n1);
+    GB_TL(1);
     GB_BARRIER();
+    GB_TL(2);
     mma(0, 0, fb0);
+    GB_TL(3);
     GB_BARRIER();
     // phase 2: A0 x B1
+    GB_TL(4);
     read_b(slot + 3 * GB_UNIT_BYTES, fb1);
     if (n1) issue(1, kt + 1);
     seg_wait(n1);
+    GB_TL(5);
     GB_BARRIER();
+    GB_TL(6);
     mma(0, 1, fb1);
+    GB_TL(7);
     GB_BARRIER();
     // phase 3: A1 x B0
+    GB_TL(8);
     read_a(slot + GB_UNIT_BYTES);
     if (n2) issue(2, kt + 2);
     seg_wait(n2);
+    GB_TL(9);
     GB_BARRIER();
+    GB_TL(10);
     mma(1, 0, fb0);
+    GB_TL(11);
     GB_BARRIER();
     // phase 4: A1 x B1
+    GB_TL(12);
     if (n2) issue(0, kt + 2);
     seg_wait(n2);
+    GB_TL(13);
     GB_BARRIER();
+    GB_TL(14);
     mma(1, 1, fb1);
+    GB_TL(15);
     GB_BARRIER();
   }
   if (wm == 0) GB_BARRIER();   // the barrier group 1 spent on the stagger
