@@ -42,8 +42,11 @@ int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_sca
 int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_scale, const void* Wf,
                       const float* w_scale, const float* s1, const float* cf, float* out, int ldo, int R, int N, int K);
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B);
-void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
-                           const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok);
+// sup_bits: the suppress list, one bit per token id, LP_SUP_WORDS 64-bit words (zero-padded past the vocabulary)
+#define LP_SUP_WORDS 896
+void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const unsigned long long* sup_bits,
+                           const int* hist2, const float* cum2, const int* d_step, const int* done, float* cand_val,
+                           int* cand_tok);
 void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val, const int* cand_tok, int* hist2,
                         float* cum2, uint8_t* kvidx2, int* cur_tok, const int* d_step, int* done, int* n_done,
                         int* n_fin, int* fin_tok, int* fin_len, float* fin_score, float* fin_cum);

@@ -296,14 +296,19 @@ template <bool I8, bool LNF, bool F32, int RT, int NT, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
     const void* __restrict__ xfv, const float* __restrict__ x_scale, const void* __restrict__ Wfv,
     const float* __restrict__ w_scale, const half_t* __restrict__ bias, const float* __restrict__ s1,
-    const float* __restrict__ cf, void* __restrict__ outv, int ldo, int R, int N, int K) {
+    const float* __restrict__ cf, void* __restrict__ outv, int ldo, int R, int N, int K, int n_rg) {
   constexpr int CH = 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int i = lane & 15, g = lane >> 4;
   const int n_rt = (R + 15) >> 4, n_ct = (N + 15) >> 4;
-  const int rt0 = (blockIdx.y * WM + wm) * RT, ct0 = (blockIdx.x * WN + wn) * NT;
+  // 1-D grid: blocks 8k .. 8k+7 are eight column groups of ONE row group, the next eight blocks the same columns
+  // of the next row group — the hardware places block b on XCD b % 8, so the n_rg workgroups that stream the
+  // same weight columns run back to back on the same XCD and all but the first find them in its L2
+  const int b8 = blockIdx.x >> 3;
+  const int cgrp = (b8 / n_rg) * 8 + (blockIdx.x & 7), rgrp = b8 % n_rg;
+  const int rt0 = (rgrp * WM + wm) * RT, ct0 = (cgrp * WN + wn) * NT;
   if (rt0 >= n_rt || ct0 >= n_ct) return;     // whole waves leave: there is no barrier in this kernel
   const int KS = K / (I8 ? 64 : 32);
   const intx4* wp[NT];
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
 // (row-shaped fragment loads of 64 B out of 16 different lines were texture-address bound).
 // The waves stride over 32-key groups with an online softmax each; merged through LDS.
 // ------------------------------------------------------------------------------------
-template <int CA_WAVES>
+template <int CA_WAVES, bool NTL>
 __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
                                                              const half_t* __restrict__ ck,
                                                              const half_t* __restrict__ cvt, int T, int kvp,
@@ -552,9 +557,13 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
     const half_t* vp = vbase + (size_t)gi * 2048;
     // K runs: q = 2*sub + s (sub: keys +0 / +4 of the interleaved A rows, s: dims 0-31 / 32-63)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) kf[q] = *reinterpret_cast<const half8_t*>(kp + q * 512);
+    for (int q = 0; q < 4; ++q)
+      kf[q] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(kp + q * 512))
+                  : *reinterpret_cast<const half8_t*>(kp + q * 512);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vf[dt] = *reinterpret_cast<const half8_t*>(vp + dt * 512);
+    for (int dt = 0; dt < 4; ++dt)
+      vf[dt] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(vp + dt * 512))
+                   : *reinterpret_cast<const half8_t*>(vp + dt * 512);
   };
   half8_t kcur[4], vcur[4], knxt[4], vnxt[4];
   if (wave < ngroups) load_kv(wave, kcur, vcur);
@@ -664,31 +673,7 @@ __global__ __launch_bounds__(1024) void dec_nospeech_kernel(const float* __restr
 // step), suppress list, [min_new_tokens], timestamp rules (a)-(e), log-softmax.
 // ------------------------------------------------------------------------------------
 #define LP_THREADS 1024
-struct PairMS { float m, s; };
-static __device__ __forceinline__ PairMS pair_add(PairMS a, float x) {
-  if (x == -INFINITY) return a;
-  if (x > a.m) { a.s = a.s * __expf(a.m - x) + 1.f; a.m = x; }
-  else a.s += __expf(x - a.m);
-  return a;
-}
-static __device__ __forceinline__ PairMS pair_merge(PairMS a, PairMS b) {
-  if (b.m == -INFINITY) return a;
-  if (a.m == -INFINITY) return b;
-  if (a.m >= b.m) { a.s += b.s * __expf(b.m - a.m); return a; }
-  b.s += a.s * __expf(a.m - b.m);
-  return b;
-}
-static __device__ __forceinline__ PairMS pair_wave(PairMS a) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    PairMS b;
-    b.m = __shfl_xor(a.m, o, 64);
-    b.s = __shfl_xor(a.s, o, 64);
-    a = pair_merge(a, b);
-  }
-  return a;
-}
-
+#define LP_WAVES (LP_THREADS / 64)
 #define LP_NV 56 /* values per thread kept in registers: V <= 56*1024 */
 // counter-based Gumbel noise: murmur3 finaliser of (seed, row, step, token) -> u strictly in (0,1) -> -log(-log u).
 // oracle/whisper.py::_gumbel restates the same integer hash.
@@ -701,23 +686,30 @@ static __device__ __forceinline__ float gumbel_noise(unsigned seed_lo, unsigned 
   const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
   return -logf(-logf(u));
 }
+
+// The row lives in registers (56 values per thread): all of its loads are issued back to back before the first use,
+// the suppress list is one bit per token (one scalar 8-byte load per 64 tokens of a wave), every element-wise rule
+// is a range test on uniform scalars.  Top-C: each thread keeps its own best (key, slot); a round is one wave
+// arg-max + 16 partials through LDS, and only the winning thread rescans its 56 values.
+template <bool SMP>
 __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::GenDev gp, float* __restrict__ logits,
-                                                                        const uint8_t* __restrict__ sup_mask,
+                                                                        const unsigned long long* __restrict__ sup_bits,
                                                                         const int* __restrict__ hist2,
                                                                         const float* __restrict__ cum2,
                                                                         const int* __restrict__ d_step,
                                                                         const int* __restrict__ done,
                                                                         float* __restrict__ cand_val,
                                                                         int* __restrict__ cand_tok) {
-  __shared__ PairMS red_t[LP_THREADS / 64], red_s[LP_THREADS / 64];
-  __shared__ float sh_lse, sh_mask_text;
-  __shared__ float bv[LP_THREADS / 64], braw[LP_THREADS / 64];
-  __shared__ int bi[LP_THREADS / 64];
-  __shared__ int win_i;
+  __shared__ float red_mt[LP_WAVES], red_ms[LP_WAVES], red_st[LP_WAVES], red_ss[LP_WAVES];
+  __shared__ float bkey_s[2][LP_WAVES];
+  __shared__ int btok_s[2][LP_WAVES];
+  __shared__ int sh_last_ts;
   const int r = blockIdx.x;
   const int c = r / gp.K;
   if (done[c]) return;
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int step = *d_step;
   const int cur = step & 1;
   const int n = step;  // tokens generated so far on this row
@@ -725,6 +717,7 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   float* lg = logits + (size_t)r * gp.V;
   const int V = gp.V, tb = gp.ts_begin;
   const float NEG = -INFINITY;
+  const int NONE = 0x7fffffff;
 
   // ---- sparse rules that touch a few ids (in HBM, before the row is pulled into registers) ----
   if (gp.rep_pen != 1.0f && n > 0) {
@@ -750,116 +743,169 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
     }
     __syncthreads();
   }
-  // ---- timestamp-rule scalars ----
-  bool last_ts = false, penult_ts = true;
-  int ts_bound = tb;  // timestamps in [tb, ts_bound) are forbidden
-  if (gp.with_ts) {
-    last_ts = n >= 1 && hist[n - 1] >= tb;
-    penult_ts = n < 2 || hist[n - 2] >= tb;
-    int last_seen = -1;
-    for (int i = n - 1; i >= 0; --i)
-      if (hist[i] >= tb) { last_seen = hist[i]; break; }
-    if (last_seen >= 0) ts_bound = (last_ts && !penult_ts) ? last_seen : last_seen + 1;
-  }
-  // ---- pass 1: load the row once, element-wise masks, (max, sumexp) over text / timestamp ids ----
+  // ---- the row: every load in flight at once ----
   float val[LP_NV];
-  PairMS pt = {NEG, 0.f}, ps = {NEG, 0.f};
 #pragma unroll
   for (int i = 0; i < LP_NV; ++i) {
     const int v = tid + i * LP_THREADS;
-    float x = NEG;
-    if (v < V) {
-      x = lg[v];
-      bool kill = sup_mask[v] != 0;
-      if (n == 0 && gp.suppress_blank) {
-        for (int q = 0; q < gp.n_sup_begin; ++q) kill |= (v == gp.sup_begin[q]);
-      }
-      if (n < gp.min_new && v == gp.eot) kill = true;
-      if (gp.with_ts) {
-        if (v == gp.no_ts) kill = true;
-        if (last_ts) {
-          if (penult_ts) { if (v >= tb) kill = true; }
-          else { if (v < gp.eot) kill = true; }
-        }
-        if (v >= tb && v < ts_bound) kill = true;
-        if (n == 0) {
-          if (v < tb) kill = true;
-          if (gp.mits >= 0 && v > tb + gp.mits) kill = true;
-        }
-      }
-      if (kill) x = NEG;
-      if (v < tb) pt = pair_add(pt, x); else ps = pair_add(ps, x);
+    val[i] = (v < V) ? lg[v] : NEG;
+  }
+  // ---- timestamp-rule scalars (uniform): the position of the last timestamp token by a block arg-max ----
+  int a_hi = 0;        // ids in [0, a_hi) are forbidden
+  int b_hi = tb;       // timestamps in [tb, b_hi) are forbidden
+  int c_lo = NONE;     // ids >= c_lo are forbidden
+  if (gp.with_ts) {
+    if (tid == 0) sh_last_ts = -1;
+    __syncthreads();
+    if (tid < n && hist[tid] >= tb) atomicMax(&sh_last_ts, tid);   // n <= n_text_ctx <= LP_THREADS
+    __syncthreads();
+    const int lp = sh_last_ts;
+    const bool last_ts = n >= 1 && lp == n - 1;
+    const bool penult_ts = n < 2 || hist[n - 2] >= tb;
+    if (lp >= 0) {
+      const int last_seen = hist[lp];
+      b_hi = (last_ts && !penult_ts) ? last_seen : last_seen + 1;
     }
+    if (last_ts) {
+      if (penult_ts) b_hi = NONE;   // a closed pair: no timestamp at all
+      else a_hi = gp.eot;           // an open one: text is forbidden, the pair has to close
+    }
+    if (n == 0) {
+      a_hi = tb;                    // the first token is a timestamp
+      if (gp.mits >= 0) c_lo = tb + gp.mits + 1;
+    }
+  }
+  const int kill_a = (n < gp.min_new) ? gp.eot : -1;
+  const int kill_b = gp.with_ts ? gp.no_ts : -1;
+  // ---- element-wise masks, class maxima (text / timestamp ids) ----
+  float mt = NEG, ms = NEG;
+#pragma unroll
+  for (int i = 0; i < LP_NV; ++i) {
+    const int v = tid + i * LP_THREADS;
+    const unsigned long long bits = sup_bits[i * LP_WAVES + wv];   // wave-uniform: tokens 64 * (i * 16 + wv) ..
+    bool kill = (bits >> lane) & 1ull;
+    kill |= (v < a_hi) | ((v >= tb) & (v < b_hi)) | (v >= c_lo) | (v == kill_a) | (v == kill_b);
+    const float x = kill ? NEG : val[i];
     val[i] = x;
+    if (v < tb) mt = fmaxf(mt, x); else ms = fmaxf(ms, x);
   }
-  pt = pair_wave(pt);
-  ps = pair_wave(ps);
-  if ((tid & 63) == 0) { red_t[tid >> 6] = pt; red_s[tid >> 6] = ps; }
-  __syncthreads();
-  if (tid == 0) {
-    PairMS a = red_t[0], b = red_s[0];
-    for (int i = 1; i < LP_THREADS / 64; ++i) { a = pair_merge(a, red_t[i]); b = pair_merge(b, red_s[i]); }
-    const float lse_s = b.m == NEG ? NEG : b.m + __logf(b.s);
-    const PairMS all = pair_merge(a, b);
-    float lse = all.m == NEG ? NEG : all.m + __logf(all.s);
-    float mask_text = 0.f;
-    // rule (e): if logsumexp(timestamps) > max(text) (in log-prob space the common lse cancels)
-    if (gp.with_ts && lse_s > a.m) { mask_text = 1.f; lse = lse_s; }
-    sh_lse = lse;
-    sh_mask_text = mask_text;
+  if (n == 0 && gp.suppress_blank && gp.n_sup_begin > 0) {   // first step only
+    mt = NEG; ms = NEG;
+    int sb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sb[q] = q < gp.n_sup_begin ? gp.sup_begin[q] : -1;
+#pragma unroll
+    for (int i = 0; i < LP_NV; ++i) {
+      const int v = tid + i * LP_THREADS;
+      bool kill = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kill |= (v == sb[q]);
+      const float x = kill ? NEG : val[i];
+      val[i] = x;
+      if (v < tb) mt = fmaxf(mt, x); else ms = fmaxf(ms, x);
+    }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mt = fmaxf(mt, __shfl_xor(mt, o, 64));
+    ms = fmaxf(ms, __shfl_xor(ms, o, 64));
+  }
+  if (lane == 0) { red_mt[wv] = mt; red_ms[wv] = ms; }
   __syncthreads();
-  const float lse = sh_lse;
-  const bool mask_text = sh_mask_text != 0.f;
-  // ---- pass 2 (registers): log-probs ----
+  float max_t = red_mt[0], max_s = red_ms[0];
+#pragma unroll
+  for (int i = 1; i < LP_WAVES; ++i) { max_t = fmaxf(max_t, red_mt[i]); max_s = fmaxf(max_s, red_ms[i]); }
+  // ---- class sums of exp(x - class max): exp(-inf) = 0 drops the masked ids ----
+  const float off_t = (max_t == NEG) ? 0.f : max_t, off_s = (max_s == NEG) ? 0.f : max_s;
+  float st = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP_NV; ++i) {
+    const int v = tid + i * LP_THREADS;
+    const bool text = v < tb;
+    const float e = __expf(val[i] - (text ? off_t : off_s));
+    if (text) st += e; else ss += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    st += __shfl_xor(st, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  if (lane == 0) { red_st[wv] = st; red_ss[wv] = ss; }
+  __syncthreads();
+  float sum_t = 0.f, sum_s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP_WAVES; ++i) { sum_t += red_st[i]; sum_s += red_ss[i]; }   // fixed order: every thread agrees
+  const float lse_t = (max_t == NEG) ? NEG : max_t + logf(sum_t);
+  const float lse_s = (max_s == NEG) ? NEG : max_s + logf(sum_s);
+  float lse;
+  if (lse_t == NEG) lse = lse_s;
+  else if (lse_s == NEG) lse = lse_t;
+  else {
+    const float hi = fmaxf(lse_t, lse_s), lo = fminf(lse_t, lse_s);
+    lse = hi + log1pf(expf(lo - hi));
+  }
+  // rule (e): if logsumexp(timestamps) > max(text) (in log-prob space the common lse cancels): text is masked
+  const bool mask_text = gp.with_ts && lse_s > max_t;
+  if (mask_text) lse = lse_s;
+  // ---- log-probs; this thread's best key ----
+  const float cum = cum2[(size_t)cur * gp.R + r];
+  constexpr bool smp = SMP;   // a separate instantiation: 2 x 56 inlined logf stay out of the beam / greedy kernel
+  const int C = smp ? 1 : 2 * gp.K;
+  float bkey = NEG;
+  int bq = -1;
 #pragma unroll
   for (int i = 0; i < LP_NV; ++i) {
     const int v = tid + i * LP_THREADS;
     float x = val[i];
     if (mask_text && v < tb) x = NEG;
-    val[i] = (x == NEG) ? NEG : x - lse;
+    x = (x == NEG) ? NEG : x - lse;
+    val[i] = x;
+    float key = x;
+    if (smp && x != NEG) key = x * gp.inv_temp + gumbel_noise(gp.seed_lo, gp.seed_hi, (unsigned)r, (unsigned)step, (unsigned)v);
+    if (key > bkey) { bkey = key; bq = i; }   // ascending index: ties keep the lowest
   }
-  // ---- top-C of cum + logp: C rounds of block arg-max (value desc, index asc).  Sampling mode
-  //      (Gumbel-max): one round on logp/T + Gumbel noise; the recorded score stays cum + logp. ----
-  const float cum = cum2[(size_t)cur * gp.R + r];
-  const bool smp = gp.sample != 0;
-  const int C = smp ? 1 : 2 * gp.K;
+  // ---- top-C of cum + logp: C rounds (value desc, index asc).  Sampling mode (Gumbel-max): one round on
+  //      logp/T + Gumbel noise; the recorded score stays cum + logp. ----
   for (int cidx = 0; cidx < C; ++cidx) {
-    float v = NEG, vraw = NEG;
-    int i = 0x7fffffff;
-#pragma unroll
-    for (int q = 0; q < LP_NV; ++q) {
-      float key = val[q];
-      if (smp && key != NEG)
-        key = key * gp.inv_temp + gumbel_noise(gp.seed_lo, gp.seed_hi, (unsigned)r, (unsigned)step,
-                                               (unsigned)(tid + q * LP_THREADS));
-      if (key > v) { v = key; vraw = val[q]; i = tid + q * LP_THREADS; }  // ascending index: ties keep the lowest
-    }
+    float k = bkey;
+    int t = (bq < 0) ? NONE : tid + bq * LP_THREADS;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(v, o, 64);
-      const float orw = __shfl_xor(vraw, o, 64);
-      const int oi = __shfl_xor(i, o, 64);
-      if (ov > v || (ov == v && oi < i)) { v = ov; vraw = orw; i = oi; }
+      const float ok = __shfl_xor(k, o, 64);
+      const int ot = __shfl_xor(t, o, 64);
+      if (ok > k || (ok == k && ot < t)) { k = ok; t = ot; }
     }
-    if ((tid & 63) == 0) { bv[tid >> 6] = v; braw[tid >> 6] = vraw; bi[tid >> 6] = i; }
+    const int par = cidx & 1;   // partials double-buffered: one barrier per round
+    if (lane == 0) { bkey_s[par][wv] = k; btok_s[par][wv] = t; }
     __syncthreads();
-    if (tid == 0) {
-      float wv = bv[0], wr = braw[0];
-      int wi = bi[0];
-      for (int q = 1; q < LP_THREADS / 64; ++q)
-        if (bv[q] > wv || (bv[q] == wv && bi[q] < wi)) { wv = bv[q]; wr = braw[q]; wi = bi[q]; }
-      win_i = wi;
-      cand_val[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? NEG : cum + wr;
-      cand_tok[(size_t)r * 32 + cidx] = (wi == 0x7fffffff) ? 0 : wi;
-      if (smp) { cand_val[(size_t)r * 32 + 1] = NEG; cand_tok[(size_t)r * 32 + 1] = 0; }
-    }
-    __syncthreads();
-    const int wi = win_i;
-    if (wi != 0x7fffffff && (wi & (LP_THREADS - 1)) == tid) {
+    float wk = bkey_s[par][0];
+    int wt = btok_s[par][0];
 #pragma unroll
-      for (int q = 0; q < LP_NV; ++q)
-        if (tid + q * LP_THREADS == wi) val[q] = NEG;
+    for (int i = 1; i < LP_WAVES; ++i) {
+      const float ok = bkey_s[par][i];
+      const int ot = btok_s[par][i];
+      if (ok > wk || (ok == wk && ot < wt)) { wk = ok; wt = ot; }
+    }
+    if (wt == NONE) {   // nothing left on this row
+      if (tid == 0) {
+        cand_val[(size_t)r * 32 + cidx] = NEG;
+        cand_tok[(size_t)r * 32 + cidx] = 0;
+        if (smp) { cand_val[(size_t)r * 32 + 1] = NEG; cand_tok[(size_t)r * 32 + 1] = 0; }
+      }
+      continue;
+    }
+    if ((wt & (LP_THREADS - 1)) == tid) {   // the winning thread: record, retire the value, find its next best
+      const int wq = wt / LP_THREADS;
+      float raw = NEG;
+      bkey = NEG; bq = -1;
+#pragma unroll
+      for (int i = 0; i < LP_NV; ++i) {
+        if (i == wq) { raw = val[i]; val[i] = NEG; }
+        if (!smp && val[i] > bkey) { bkey = val[i]; bq = i; }
+      }
+      cand_val[(size_t)r * 32 + cidx] = cum + raw;
+      cand_tok[(size_t)r * 32 + cidx] = wt;
+      if (smp) { cand_val[(size_t)r * 32 + 1] = NEG; cand_tok[(size_t)r * 32 + 1] = 0; }
     }
   }
 }
@@ -1102,9 +1148,10 @@ static void wave_go(hipStream_t st, const void* xf, const float* x_scale, const 
                     const float* s1, const float* cf, float* out, int ldo, int R, int N, int K) {
   constexpr int NT = 2, WM = 1, WN = 4;
   const int n_rt = (R + 15) / 16, n_ct = (N + 15) / 16;
-  const dim3 grid((n_ct + NT * WN - 1) / (NT * WN), (n_rt + RT * WM - 1) / (RT * WM));
-  dec_gemm_wave_kernel<I8, LNF, true, RT, NT, WM, WN><<<grid, WM * WN * 64, 0, st>>>(xf, x_scale, Wf, w_scale, nullptr, s1,
-                                                                                     cf, out, ldo, R, N, K);
+  const int n_cg = ((n_ct + NT * WN - 1) / (NT * WN) + 7) & ~7;   // padded to whole groups of 8 (extra waves leave)
+  const int n_rg = (n_rt + RT * WM - 1) / (RT * WM);
+  dec_gemm_wave_kernel<I8, LNF, true, RT, NT, WM, WN><<<n_cg * n_rg, WM * WN * 64, 0, st>>>(
+      xf, x_scale, Wf, w_scale, nullptr, s1, cf, out, ldo, R, N, K, n_rg);
 }
 
 // Vocabulary projection -> float32 logits [R][ldo].  fp16: xf = the raw residual stream, fragment-major, with the
@@ -1124,7 +1171,7 @@ int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_sc
   else if (n_rt == 2) WG(2);
   else if (n_rt == 3) WG(3);
   else if (n_rt == 4) WG(4);
-  else WG(5);   // 5 row tiles = the 80 rows of a 16-chunk beam-5 step per wave; more rows: row groups on grid.y
+  else WG(5);   // 5 row tiles = the 80 rows of a 16-chunk beam-5 step per wave; more rows: further row groups
 #undef WG
   return 0;
 }
@@ -1139,17 +1186,24 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag) {
   // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup (4 waves measured slower)
-  dec_cross_attn_kernel<8><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
+  static const bool nt = getenv("FWAMD_CA_NT") != nullptr;   // experiment: non-temporal K / V^T stream
+  if (nt) dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
+  else dec_cross_attn_kernel<8, false><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {
   dec_nospeech_kernel<<<B, 1024, 0, st>>>(logits, V, row_mul, no_speech_id, out);
 }
 
-void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const uint8_t* sup_mask, const int* hist2,
-                           const float* cum2, const int* d_step, const int* done, float* cand_val, int* cand_tok) {
-  dec_logits_process_kernel<<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_mask, hist2, cum2, d_step, done, cand_val,
-                                                         cand_tok);
+void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const unsigned long long* sup_bits,
+                           const int* hist2, const float* cum2, const int* d_step, const int* done, float* cand_val,
+                           int* cand_tok) {
+  if (gp.sample)
+    dec_logits_process_kernel<true><<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_bits, hist2, cum2, d_step, done,
+                                                                 cand_val, cand_tok);
+  else
+    dec_logits_process_kernel<false><<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_bits, hist2, cum2, d_step, done,
+                                                                  cand_val, cand_tok);
 }
 
 void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val, const int* cand_tok, int* hist2,

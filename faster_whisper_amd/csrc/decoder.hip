@@ -62,7 +62,7 @@ struct GenWorkspace {
   float *fin_score = nullptr, *fin_cum = nullptr;
   int* d_step = nullptr;
   float* no_speech = nullptr;
-  uint8_t* sup_mask = nullptr;
+  unsigned long long* sup_bits = nullptr;   // suppress list, one bit per token id
   int* zero_done = nullptr;              // [R] zeros (kernels that take a `done` pointer outside generate)
   half_t *x_frag = nullptr, *att_frag = nullptr, *ffn_frag = nullptr;   // fragment-major GEMM inputs (fp16)
   int8_t* xq = nullptr;                  // int8_float16: quantised linear input, fragment-major [R16][4d]
@@ -128,7 +128,7 @@ int gen_workspace_ensure(Model* m) {
   A(g->fin_score, R * FIN_CAP); A(g->fin_cum, R * FIN_CAP);
   A(g->d_step, 1);
   A(g->no_speech, R);
-  A(g->sup_mask, (size_t)c.n_vocab);
+  A(g->sup_bits, (size_t)LP_SUP_WORDS);
   A(g->zero_done, R);
   const size_t R16 = (R + 15) / 16 * 16;   // whole 16-row tiles
   if (m->compute_type == FW_COMPUTE_INT8_FLOAT16) {
@@ -163,7 +163,7 @@ void gen_workspace_free(Model* m) {
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
   void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
-                  g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_mask,
+                  g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_bits,
                   g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -335,7 +335,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   }
   if (s.beam_tail) {
     ProfScope ps(m, PF_DEC_SAMPLE, 0, 8.0 * rows * c.n_vocab, st);
-    fwd::launch_logits_process(st, gp, g->logits, g->sup_mask, g->hist2, g->cum2, g->d_step, g->done, g->cand_val,
+    fwd::launch_logits_process(st, gp, g->logits, g->sup_bits, g->hist2, g->cum2, g->d_step, g->done, g->cand_val,
                                g->cand_tok);
     fwd::launch_beam_update(st, gp, g->cand_val, g->cand_tok, g->hist2, g->cum2, g->kvidx2, g->cur_tok, g->d_step,
                             g->done, g->n_done, g->n_fin, g->fin_tok, g->fin_len, g->fin_score, g->fin_cum);
@@ -452,12 +452,12 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   FW_HIP(hipMemsetAsync(g->n_fin, 0, Rr * sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
   FW_HIP(hipMemsetAsync(g->no_speech, 0, Rr * sizeof(float), st));
-  std::vector<uint8_t> mask(c.n_vocab, 0);
+  std::vector<unsigned long long> mask(LP_SUP_WORDS, 0ull);
   for (int i = 0; i < o->n_suppress_tokens; ++i) {
     const int t = o->suppress_tokens[i];
-    if (t >= 0 && t < c.n_vocab) mask[t] = 1;
+    if (t >= 0 && t < c.n_vocab) mask[t >> 6] |= 1ull << (t & 63);
   }
-  FW_HIP(hipMemcpyAsync(g->sup_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
+  FW_HIP(hipMemcpyAsync(g->sup_bits, mask.data(), mask.size() * sizeof(mask[0]), hipMemcpyHostToDevice, st));
   // prompt tokens transposed to [pos][bx]; first-step tokens replicated per beam
   std::vector<int> ptok((size_t)P * Bx), first((size_t)Bx * K);
   {
