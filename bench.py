@@ -115,6 +115,8 @@ def build_backend(args, cfg, rank, world, local_rank):
     ct = 1 if args.compute_type == "int8_float16" else 0
     common = dict(device="cuda", device_index=local_rank, max_batch_size=args.batch, max_beam_size=args.beam,
                   inter_threads=args.workers, compute_type=args.compute_type)
+    if args.encoder_cus is not None:
+        common["encoder_cus"] = args.encoder_cus
     weights = None
     if world > 1:
         blob = None
@@ -149,6 +151,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--encoder-cus", type=int, default=None,
+                    help="confine the encoder streams to this many CUs (default: the backend's; 0 = no confinement)")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=100)
@@ -275,6 +279,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                    "decode_group": {"capacity_chunks": stats1["decode_batch"], "decode_runs": runs,
                                     "chunks_per_run": round((stats1["chunks"] - stats0["chunks"]) / runs, 1),
                                     "largest_run_chunks": stats1["max_run_chunks"]},
+                   "encoder_cus": getattr(model, "_encoder_cus", 0),
                    "model_load_s": round(load_s, 1)},
     }
 

@@ -25,6 +25,9 @@ from . import _lib
 from .config import WhisperConfig, get_config
 from .weights import synthetic_weights, weight_shapes
 
+# CUs the encoder streams of a multi-worker device are confined to (0 = no confinement); see Whisper.__init__
+ENCODER_CUS_DEFAULT = 0
+
 _COMPUTE_TYPES = {
     "default": _lib.COMPUTE_FLOAT16, "auto": _lib.COMPUTE_FLOAT16, "float16": _lib.COMPUTE_FLOAT16,
     "int8_float16": _lib.COMPUTE_INT8_FLOAT16, "int8": _lib.COMPUTE_INT8_FLOAT16,
@@ -251,8 +254,15 @@ class Whisper:
         # The workers of a device form a DECODE GROUP (include/fwamd.h): they share one decode workspace sized
         # for all of their batches, and generate() calls that arrive concurrently are merged into one decode run
         # whose rows share every weight byte streamed per step.  decode_group=False keeps a decoder per worker.
+        # encoder_cus: with several workers the encoder streams are confined to that many CUs so that the decode
+        # run always has the rest of the chip (fwamd.h: fw_model_set_encoder_cus); None = the measured default
         self._replicas = []
         decode_group = bool(kwargs.pop("decode_group", True))
+        encoder_cus = kwargs.pop("encoder_cus", None)
+        if encoder_cus is None:
+            encoder_cus = int(os.environ.get("FWAMD_ENCODER_CUS", ENCODER_CUS_DEFAULT)) \
+                if (decode_group and inter_threads > 1) else 0
+        self._encoder_cus = int(encoder_cus)
         for i in idx:
             primary = _Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev)
             self._replicas.append(primary)
@@ -266,6 +276,9 @@ class Whisper:
                     if decode_group:
                         _lib.check(self._lib.fw_model_join_decoder(r.handle, primary.handle))
                     self._replicas.append(r)
+        if self._encoder_cus:
+            for r in self._replicas:
+                _lib.check(self._lib.fw_model_set_encoder_cus(r.handle, self._encoder_cus))
         self._seed_counter = itertools.count(1)
         self._rr = itertools.count()
         self._tls = threading.local()
@@ -399,10 +412,12 @@ class Whisper:
     def log_mel(self, chunks: Sequence[np.ndarray]) -> np.ndarray:
         """FeatureExtractor(chunk)[..., :-1] + pad_or_trim for a batch of chunks, on the GPU."""
         rep = self._replica_for(None)
-        pcm, offs = _ragged(chunks, np.float32)
         out = np.empty((len(chunks), self._cfg.n_mels, 3000), dtype=np.float32)
-        _lib.check(self._lib.fw_logmel(rep.handle, _lib.ptr(pcm), _lib.as_i64p(offs), len(chunks), _lib.ptr(out),
-                                       None))
+        for b0 in range(0, len(chunks), self._max_batch):      # the engine's workspaces hold max_batch_size chunks
+            part = chunks[b0:b0 + self._max_batch]
+            pcm, offs = _ragged(part, np.float32)
+            _lib.check(self._lib.fw_logmel(rep.handle, _lib.ptr(pcm), _lib.as_i64p(offs), len(part),
+                                           _lib.ptr(out[b0:b0 + len(part)]), None))
         return out
 
     def log_mel_full(self, waveform: np.ndarray) -> np.ndarray:

@@ -716,6 +716,96 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   return req.rc;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Test hook: ONE launch of the logits-rules kernel (rules, log-softmax, top-2K / Gumbel arg-max) on caller-provided
+// logits and row state, outside any decode run: tests/test_gpu_logits_rules.py compares the candidates with the
+// oracle's rule restatement id for id.  rows = R (row r belongs to chunk r / beam_size), n = tokens generated so far
+// (the same for every row), hist [R][n], cum [R]; out: cand_val / cand_tok [R][2 * beam_size] (sampling: [R][1]).
+// ---------------------------------------------------------------------------------------------------
+int32_t fw_test_logits_rules(fw_model* fm, const float* logits, int32_t R, const int32_t* hist, int32_t n,
+                             const float* cum, const fw_gen_opts* o, int32_t with_timestamps, float* cand_val,
+                             int32_t* cand_tok) {
+  FW_CHECK_ARG(fm && logits && cum && o && cand_val && cand_tok && R >= 1 && n >= 0, "bad arguments");
+  Model* m = &fm->impl;
+  const fw_config& c = m->cfg;
+  const int K = o->beam_size;
+  const bool sampling = K == 1 && o->sampling_topk != 1;
+  FW_CHECK_ARG(K >= 1 && K <= 16 && R % K == 0 && n < c.n_text_ctx && (n == 0 || hist), "bad geometry");
+  FW_CHECK_ARG(c.n_vocab <= LP_SUP_WORDS * 64, "vocabulary too large for the rules kernel");
+  FW_HIP(hipSetDevice(m->device));
+  GenDev gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.B = R / K; gp.K = K; gp.R = R; gp.V = c.n_vocab; gp.n_text_ctx = c.n_text_ctx;
+  gp.sample = sampling ? 1 : 0;
+  gp.inv_temp = sampling ? 1.0f / o->sampling_temperature : 1.0f;
+  gp.seed_lo = (unsigned)(o->seed & 0xffffffffu);
+  gp.seed_hi = (unsigned)(o->seed >> 32);
+  gp.with_ts = with_timestamps ? 1 : 0;
+  gp.suppress_blank = o->suppress_blank ? 1 : 0;
+  gp.min_new = o->min_new_tokens;
+  gp.mits = o->max_initial_timestamp_index;
+  gp.ngram = o->no_repeat_ngram_size;
+  gp.rep_pen = o->repetition_penalty;
+  gp.eot = c.tok_eot; gp.no_ts = c.tok_no_timestamps; gp.ts_begin = c.tok_timestamp_begin;
+  gp.n_sup_begin = c.n_suppress_begin;
+  for (int i = 0; i < c.n_suppress_begin; ++i) gp.sup_begin[i] = c.suppress_begin[i];
+  std::vector<unsigned long long> mask(LP_SUP_WORDS, 0ull);
+  for (int i = 0; i < o->n_suppress_tokens; ++i) {
+    const int t = o->suppress_tokens[i];
+    if (t >= 0 && t < c.n_vocab) mask[t >> 6] |= 1ull << (t & 63);
+  }
+  const size_t NT = (size_t)c.n_text_ctx;
+  std::vector<int> h2(2 * (size_t)R * NT, 0);
+  std::vector<float> c2(2 * (size_t)R, 0.f);
+  const int cur = n & 1;   // the kernel reads the half selected by the step's parity
+  for (int r = 0; r < R; ++r) {
+    for (int i = 0; i < n; ++i) h2[((size_t)cur * R + r) * NT + i] = hist[(size_t)r * n + i];
+    c2[(size_t)cur * R + r] = cum[r];
+  }
+  float *d_lg = nullptr, *d_cum = nullptr, *d_cv = nullptr;
+  int *d_hist = nullptr, *d_step = nullptr, *d_done = nullptr, *d_ct = nullptr;
+  unsigned long long* d_bits = nullptr;
+  int rc = FW_OK;
+  auto cleanup = [&]() {
+    (void)hipFree(d_lg); (void)hipFree(d_cum); (void)hipFree(d_cv); (void)hipFree(d_hist); (void)hipFree(d_step);
+    (void)hipFree(d_done); (void)hipFree(d_ct); (void)hipFree(d_bits);
+  };
+#define TH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s: %s", #call, hipGetErrorString(e_)); cleanup(); return FW_ENODEV; } } while (0)
+  const size_t lg_bytes = (size_t)R * c.n_vocab * sizeof(float);
+  TH(hipMalloc(&d_lg, lg_bytes));
+  TH(hipMalloc(&d_cum, c2.size() * sizeof(float)));
+  TH(hipMalloc(&d_cv, (size_t)R * 32 * sizeof(float)));
+  TH(hipMalloc(&d_ct, (size_t)R * 32 * sizeof(int)));
+  TH(hipMalloc(&d_hist, h2.size() * sizeof(int)));
+  TH(hipMalloc(&d_step, sizeof(int)));
+  TH(hipMalloc(&d_done, (size_t)R * sizeof(int)));
+  TH(hipMalloc(&d_bits, mask.size() * sizeof(mask[0])));
+  TH(hipMemcpy(d_lg, logits, lg_bytes, hipMemcpyHostToDevice));
+  TH(hipMemcpy(d_cum, c2.data(), c2.size() * sizeof(float), hipMemcpyHostToDevice));
+  TH(hipMemcpy(d_hist, h2.data(), h2.size() * sizeof(int), hipMemcpyHostToDevice));
+  TH(hipMemcpy(d_step, &n, sizeof(int), hipMemcpyHostToDevice));
+  TH(hipMemset(d_done, 0, (size_t)R * sizeof(int)));
+  TH(hipMemset(d_cv, 0, (size_t)R * 32 * sizeof(float)));
+  TH(hipMemset(d_ct, 0, (size_t)R * 32 * sizeof(int)));
+  TH(hipMemcpy(d_bits, mask.data(), mask.size() * sizeof(mask[0]), hipMemcpyHostToDevice));
+  fwd::launch_logits_process(nullptr, gp, d_lg, d_bits, d_hist, d_cum, d_step, d_done, d_cv, d_ct);
+  TH(hipGetLastError());
+  TH(hipDeviceSynchronize());
+  const int C = sampling ? 1 : 2 * K;
+  std::vector<float> hv((size_t)R * 32);
+  std::vector<int> ht((size_t)R * 32);
+  TH(hipMemcpy(hv.data(), d_cv, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
+  TH(hipMemcpy(ht.data(), d_ct, ht.size() * sizeof(int), hipMemcpyDeviceToHost));
+#undef TH
+  for (int r = 0; r < R; ++r)
+    for (int j = 0; j < C; ++j) {
+      cand_val[(size_t)r * C + j] = hv[(size_t)r * 32 + j];
+      cand_tok[(size_t)r * C + j] = ht[(size_t)r * 32 + j];
+    }
+  cleanup();
+  return rc;
+}
+
 int32_t fw_detect_language(fw_model* fm, const fw_tensor* enc_t, int32_t B, int32_t* out_lang_ids,
                            float* out_probs) {
   FW_CHECK_ARG(fm && enc_t && out_lang_ids && out_probs, "null argument");

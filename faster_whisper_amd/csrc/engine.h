@@ -165,6 +165,7 @@ struct Model {
   GenWorkspace* gen = nullptr;
   Model* decoder = nullptr;
   int decode_batch = 0;
+  int encoder_cus = 0;       // CUs the encoder stream is confined to (0 = all): fw_model_set_encoder_cus
   hipStream_t dec_stream = nullptr;
   std::mutex dec_mu;
   DecodeGroup grp;

@@ -1084,6 +1084,45 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   return gen_workspace_ensure(m);
 }
 
+// CU mask of n CUs spread evenly over the 8 XCDs.  Whether bit i of a HIP CU mask is CU (i % 32) of XCD (i / 32)
+// or CU (i / 8) of XCD (i % 8) is not documented; this pattern selects 4k + j CUs of every XCD under either
+// reading (n = 32k + 8j): key = (i%8 + i/8) % 8 < k picks k of every 8 in both, the partial class is split by
+// ((i/8)%4 + i/64) % 4 < j which runs over all four values inside an XCD in both.
+static void balanced_cu_mask(int n_cus, uint32_t mask[8]) {
+  const int k = n_cus / 32, j = (n_cus % 32) / 8;
+  for (int w = 0; w < 8; ++w) mask[w] = 0;
+  for (int i = 0; i < 256; ++i) {
+    const int a = i % 8, b = i / 8;
+    const int key = (a + b) % 8;
+    if (key < k || (key == k && ((b % 4) + (b / 8)) % 4 < j)) mask[i >> 5] |= 1u << (i & 31);
+  }
+}
+
+int32_t fw_model_set_encoder_cus(fw_model* fm, int32_t n_cus) {
+  FW_CHECK_ARG(fm, "null model");
+  Model* m = &fm->impl;
+  FW_CHECK_ARG(n_cus == 0 || (n_cus >= 32 && n_cus <= 256 && n_cus % 8 == 0),
+               "encoder CUs: 0 (all) or a multiple of 8 in [32, 256]");
+  FW_HIP(hipSetDevice(m->device));
+  hipStream_t fresh = nullptr;
+  if (n_cus == 0 || n_cus == 256) {
+    FW_HIP(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+  } else {
+    uint32_t mask[8];
+    balanced_cu_mask(n_cus, mask);
+    FW_HIP(hipExtStreamCreateWithCUMask(&fresh, 8, mask));
+  }
+  if (m->stream) {
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipStreamDestroy(m->stream);
+  }
+  m->stream = fresh;
+  m->encoder_cus = (n_cus == 256) ? 0 : n_cus;
+  return FW_OK;
+}
+
+int32_t fw_model_encoder_cus(const fw_model* fm) { return fm ? fm->impl.encoder_cus : 0; }
+
 int32_t fw_model_decode_batch(const fw_model* fm) {
   if (!fm) return 0;
   const Model* m = fm->impl.decoder ? fm->impl.decoder : &fm->impl;

@@ -165,6 +165,15 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
 int32_t fw_model_set_decode_batch(fw_model* m, int32_t decode_batch);
 int32_t fw_model_decode_batch(const fw_model* m);
 int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
+/* Compute-unit partition between the encoder and the decode group of a device.  The encoder GEMM is MFMA-bound and
+ * holds a CU's whole register file and LDS; the decode step is HBM- and latency-bound and cannot co-reside with it.
+ * Left alone the two time-slice the chip (wall = encoder + decode).  Confining the ENCODER stream of every replica
+ * to n_cus CUs (a multiple of 8 in [32, 256], spread evenly over the XCDs; 0 = no confinement) leaves the other
+ * CUs to the decode run at all times, so the two overlap.  Recreates the model's encoder stream: call it after
+ * fw_model_create and before the first encode, from one thread.  (No counterpart in the reference: CTranslate2
+ * replicas share a GPU through the driver's time slicing, transcribe.py:645-657.) */
+int32_t fw_model_set_encoder_cus(fw_model* m, int32_t n_cus);
+int32_t fw_model_encoder_cus(const fw_model* m);
 /* counters of the decode group `m` belongs to: decode runs, fw_generate calls served, chunks decoded, chunks of
  * the largest run (any pointer may be NULL) */
 int32_t fw_model_decode_stats(const fw_model* m, int64_t* runs, int64_t* requests, int64_t* chunks,
@@ -274,6 +283,14 @@ int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const fl
 /* the vocabulary projection of a decode step: x [R][d] raw residual rows -> float32 logits [R][n_vocab] (final
  * LayerNorm folded in fp16 mode, applied by the row quantiser in int8_float16 mode), with the model's own weights */
 int32_t fw_test_dec_logits(fw_model* m, const float* x, int32_t R, float* out);
+/* one launch of the logits-rules kernel (suppress lists, repetition penalty, no-repeat n-gram, timestamp rules,
+ * log-softmax, top-2K candidates of cum + logp, or the Gumbel arg-max when opts selects sampling) on caller-provided
+ * logits [R][n_vocab] and row state: hist [R][n] = the n tokens generated so far on each row, cum [R].  Outputs
+ * cand_val / cand_tok [R][2 * beam_size] ([R][1] when sampling).  Replaces nothing in the reference: it exposes the
+ * device form of CTranslate2's logits processors to tests/test_gpu_logits_rules.py. */
+int32_t fw_test_logits_rules(fw_model* m, const float* logits, int32_t R, const int32_t* hist, int32_t n,
+                             const float* cum, const fw_gen_opts* opts, int32_t with_timestamps, float* cand_val,
+                             int32_t* cand_tok);
 /* measurement hook (profiles/gemm_bench.py): average milliseconds of one launch of the "many rows" GEMM
  * C[batch][M][N] = A[batch][M][K] W[N][K]^T on device-resident pseudo-random operands (fp16, or int8 on an
  * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
