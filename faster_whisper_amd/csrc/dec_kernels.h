@@ -35,6 +35,9 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act);
+int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
+                                 const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
+                                 int K);
 int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_scale, const int8_t* Wq,
                             const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
                             int R, int N, int K, int act);

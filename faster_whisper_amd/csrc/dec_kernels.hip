@@ -59,7 +59,7 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
 //     so a weight tile is fetched from HBM once and re-read from that XCD's L2;
 //   * fixed-order reduction of the WAVES partial tiles through 4 KB of LDS, epilogue by wave 0.
 // ------------------------------------------------------------------------------------
-template <int WAVES, bool LNF, int RT, int NT>
+template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
   // registers and cut the L2 re-reads at the price of fewer workgroups — experiment knobs, see the launcher)
   __shared__ float red[WAVES][RT * NT][64][4];
   __shared__ float red_s[WAVES][RT][16][2];
-  constexpr int CH = 20 / (RT + NT);   // k-steps in flight per wave: (RT + NT) * CH * 16 B per lane
+  constexpr int CH = CH_ ? CH_ : 20 / (RT + NT);   // k-steps in flight per wave: (RT + NT) * CH * 16 B per lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -409,55 +409,82 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// K13: decoder self-attention for one (row, head), KV cache with slot indirection.
-// cache layout [slot][H][n_ctx][64].  The new K/V (position pos) are written to the row's
-// own slot; older positions are read from kvidx[row][p] (slot inside the chunk).
-// QK: one key per lane (128-byte row = 8 x 16-byte loads); PV: 8 lanes cover the 128-byte
-// V row of a position (16 bytes each), 8 position groups in flight, shuffle-reduced.
+// K13: decoder self-attention, KV cache with slot indirection.  cache layout [slot][H][n_ctx][64].  The new K/V
+// (position pos) are written to the row's own slot; older positions are read from kvidx[row][p] (slot inside the
+// chunk).  One workgroup = (head, chunk), one wave per beam row of the chunk: the beams of a chunk share most of
+// their history (kvidx points them at the same slots), so the rows a wave fetches are in the CU's L1 / the XCD's L2
+// when its sibling asks for them.  QK and PV both read a position's 128-byte row with 8 lanes x 16 bytes (every
+// load instruction = 8 whole rows, 8 position groups per wave, 4 loads in flight per lane), reduced by shuffles.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
-                                                           half_t* __restrict__ vc, int n_ctx, int H,
-                                                           const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
-                                                           half_t* __restrict__ out, const int* __restrict__ d_step,
-                                                           int pos_fixed, int P, int R_total, int frag) {
-  __shared__ float sq[64];
-  __shared__ float sp[448];
-  __shared__ int ssrc[448];
-  const int lane = threadIdx.x;
-  const int h = blockIdx.x, r = blockIdx.y;
+#define SA_MAX_CTX 448
+__global__ __launch_bounds__(1024) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
+                                                             half_t* __restrict__ vc, int n_ctx, int H,
+                                                             const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
+                                                             half_t* __restrict__ out, const int* __restrict__ d_step,
+                                                             int pos_fixed, int P, int R_total, int frag) {
+  extern __shared__ float sa_smem[];            // per wave: sp[n_ctx] floats, ssrc[n_ctx] ints
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sp = sa_smem + (size_t)wave * 2 * n_ctx;
+  int* ssrc = reinterpret_cast<int*>(sp + n_ctx);
+  const int h = blockIdx.x, c = blockIdx.y;
+  const int r = c * kmul + wave, kb = wave;
   const int step = *d_step;
   const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + step;
-  const int c = r / kmul, kb = r - c * kmul;
   const int slot = c * Kbeam + kb;
   const int cur = (pos_fixed >= 0) ? 0 : (step & 1);
   const uint8_t* kvidx = kvidx2 + ((size_t)cur * R_total + slot) * n_ctx;
   const half_t* qr = qkv + (size_t)r * 3 * d + h * 64;
-  const float q = (float)qr[lane] * 0.125f;
-  const half_t knew = qr[d + lane], vnew = qr[2 * d + lane];
   const size_t head_stride = (size_t)n_ctx * 64;
   const size_t slot_stride = (size_t)H * head_stride;
-  kc[slot * slot_stride + h * head_stride + (size_t)pos * 64 + lane] = knew;
-  vc[slot * slot_stride + h * head_stride + (size_t)pos * 64 + lane] = vnew;
-  sq[lane] = q;
-  __syncthreads();
-  const float s_new = wave_sum(q * (float)knew);
+  const int pg = lane >> 3, cc = lane & 7;     // position group, 16-byte chunk of the 128-byte row
+  // this lane's 8 dims of q (scaled), k_new, v_new
+  const half8_t q8 = *reinterpret_cast<const half8_t*>(qr + cc * 8);
+  const half8_t kn8 = *reinterpret_cast<const half8_t*>(qr + d + cc * 8);
+  const half8_t vn8 = *reinterpret_cast<const half8_t*>(qr + 2 * d + cc * 8);
+  float q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] = (float)q8[e] * 0.125f;
+  if (pg == 0) {
+    *reinterpret_cast<half8_t*>(kc + slot * slot_stride + h * head_stride + (size_t)pos * 64 + cc * 8) = kn8;
+    *reinterpret_cast<half8_t*>(vc + slot * slot_stride + h * head_stride + (size_t)pos * 64 + cc * 8) = vn8;
+  }
+  auto dot8 = [&](const half8_t& k) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sacc += q[e] * (float)k[e];
+    sacc += __shfl_xor(sacc, 1, 64);
+    sacc += __shfl_xor(sacc, 2, 64);
+    sacc += __shfl_xor(sacc, 4, 64);
+    return sacc;                               // the 8 lanes of a position all hold its score
+  };
+  const float s_new = dot8(kn8);
   float mx = s_new;
-  for (int p = lane; p < pos; p += 64) {
-    const int src = c * Kbeam + kvidx[p];
-    ssrc[p] = src;
-    const half8_t* kr = reinterpret_cast<const half8_t*>(kc + src * slot_stride + h * head_stride + (size_t)p * 64);
-    half8_t kv[8];
+  const half_t* kbase = kc + h * head_stride + cc * 8;
+  for (int p0 = 0; p0 < pos; p0 += 32) {
+    half8_t kv[4];
+    int src[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kv[j] = kr[j];
-    float s = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const int p = p0 + 8 * j + pg;
+      const int pc = p < pos ? p : pos - 1;    // clamped: a tail slot re-reads the last position, unused
+      src[j] = c * Kbeam + kvidx[pc];
+      kv[j] = *reinterpret_cast<const half8_t*>(kbase + src[j] * slot_stride + (size_t)pc * 64);
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += sq[j * 8 + e] * (float)kv[j][e];
-    sp[p] = s;
-    mx = fmaxf(mx, s);
+    for (int j = 0; j < 4; ++j) {
+      const int p = p0 + 8 * j + pg;
+      const float sc = dot8(kv[j]);
+      if (p < pos) {
+        if (cc == 0) { sp[p] = sc; ssrc[p] = src[j]; }
+        mx = fmaxf(mx, sc);
+      }
+    }
   }
   mx = wave_max(mx);
+  // sp / ssrc are private to the wave and a wave's LDS operations execute in order: no workgroup barrier, only a
+  // compiler-level one so that the cross-lane reads below are not moved above the writes
+  __builtin_amdgcn_wave_barrier();
   float sum = 0.f;
   for (int p = lane; p < pos; p += 64) {
     const float e = __expf(sp[p] - mx);
@@ -466,8 +493,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
   }
   const float e_new = __expf(s_new - mx);
   sum = wave_sum(sum) + e_new;
-  __syncthreads();
-  const int pg = lane >> 3, cc = lane & 7;
+  __builtin_amdgcn_wave_barrier();
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -488,11 +514,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restr
     acc[e] = a;
   }
   if (pg == 0) {
-    const half8_t vn = *reinterpret_cast<const half8_t*>(qr + 2 * d + cc * 8);
     const float inv = 1.f / sum;
     half8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)((acc[e] + e_new * (float)vn[e]) * inv);
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((acc[e] + e_new * (float)vn8[e]) * inv);
     half_t* dst = frag ? out + frag_off(r, h * 64 + cc * 8, d >> 5) : out + (size_t)r * d + h * 64 + cc * 8;
     *reinterpret_cast<half8_t*>(dst) = o;
   }
@@ -1114,6 +1139,38 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
                                                                K, act);
 }
 
+// tile-shape experiments of profiles/dec_linear_bench.py (fw_bench_dec_linear): variant -> instantiation
+template <int WAVES, int RT, int NT, int CH>
+static void frag_variant(hipStream_t st, bool lnf, const half_t* xf, const half_t* Wf, const half_t* bias,
+                         const float* s1, const float* cf, half_t* out, int R, int N, int K) {
+  const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
+  if (lnf)
+    dec_gemm_frag_kernel<WAVES, true, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, s1, cf, nullptr, 0, out, N,
+                                                                              nullptr, R, N, K, 0);
+  else
+    dec_gemm_frag_kernel<WAVES, false, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, nullptr, nullptr, nullptr,
+                                                                               0, out, N, nullptr, R, N, K, 0);
+}
+int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
+                                 const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
+                                 int K) {
+  if (K % 32 != 0 || N % 64 != 0 || R < 1) return -1;
+  switch (variant) {
+    case 0: frag_variant<4, 2, 2, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;   // product, K < 2560
+    case 1: frag_variant<8, 2, 2, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;   // product, K >= 2560
+    case 2: frag_variant<8, 4, 2, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 3: frag_variant<8, 4, 2, 4>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 4: frag_variant<8, 4, 4, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 5: frag_variant<8, 4, 4, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 6: frag_variant<4, 4, 2, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 7: frag_variant<8, 2, 4, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 8: frag_variant<8, 8, 2, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 9: frag_variant<4, 4, 4, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    default: return -1;
+  }
+  return 0;
+}
+
 // The per-layer decoder linears: K split over the waves of a workgroup, 2 x 2 tiles of 16 x 16 per workgroup
 // (measured best of {1,2} x {1,2}: profiles/r01_sweep_dec_gemm_frag_tiles.jsonl), row groups on grid.y so any
 // number of rows works (a merged decode run carries up to 128 chunks x 5 beams).  out (row-major) and out_frag
@@ -1179,16 +1236,17 @@ int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_sc
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag) {
-  dec_self_attn_kernel<<<dim3(H, rows), 64, 0, st>>>(qkv, d, kc, vc, n_ctx, H, kvidx2, Kbeam, kmul, out, d_step,
-                                                     pos_fixed, P, R_total, frag);
+  // one workgroup per (head, chunk), one wave per row of the chunk (kmul <= 16); LDS: scores + source slots per wave
+  dec_self_attn_kernel<<<dim3(H, rows / kmul), kmul * 64, (size_t)kmul * 2 * n_ctx * sizeof(float), st>>>(
+      qkv, d, kc, vc, n_ctx, H, kvidx2, Kbeam, kmul, out, d_step, pos_fixed, P, R_total, frag);
 }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag) {
   // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup (4 waves measured slower)
-  static const bool nt = getenv("FWAMD_CA_NT") != nullptr;   // experiment: non-temporal K / V^T stream
-  if (nt) dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
-  else dec_cross_attn_kernel<8, false><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
+  // the K / V^T stream is read once per step and never again before 15 GB of other chunks have passed: non-temporal
+  // loads (measured 75.3 -> 68.3 ms per batch, 5.4 -> 5.9 TB/s)
+  dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {

@@ -555,11 +555,14 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   std::vector<int> n_fin(Bx), fin_len((size_t)Bx * FIN_CAP);
   std::vector<float> fin_score((size_t)Bx * FIN_CAP), nsp(Bx);
   std::vector<int> fin_tok((size_t)Bx * FIN_CAP * NT);
-  FW_HIP(hipMemcpy(n_fin.data(), g->n_fin, Bx * sizeof(int), hipMemcpyDeviceToHost));
-  FW_HIP(hipMemcpy(fin_len.data(), g->fin_len, fin_len.size() * sizeof(int), hipMemcpyDeviceToHost));
-  FW_HIP(hipMemcpy(fin_score.data(), g->fin_score, fin_score.size() * sizeof(float), hipMemcpyDeviceToHost));
-  FW_HIP(hipMemcpy(fin_tok.data(), g->fin_tok, fin_tok.size() * sizeof(int), hipMemcpyDeviceToHost));
-  FW_HIP(hipMemcpy(nsp.data(), g->no_speech, Bx * sizeof(float), hipMemcpyDeviceToHost));
+  // (on the decode stream, not the legacy default stream: a default-stream copy would wait for every BLOCKING
+  //  stream of the device, and the CU-masked encoder streams of fw_model_set_encoder_cus are blocking streams)
+  FW_HIP(hipMemcpyAsync(n_fin.data(), g->n_fin, Bx * sizeof(int), hipMemcpyDeviceToHost, st));
+  FW_HIP(hipMemcpyAsync(fin_len.data(), g->fin_len, fin_len.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  FW_HIP(hipMemcpyAsync(fin_score.data(), g->fin_score, fin_score.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  FW_HIP(hipMemcpyAsync(fin_tok.data(), g->fin_tok, fin_tok.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  FW_HIP(hipMemcpyAsync(nsp.data(), g->no_speech, Bx * sizeof(float), hipMemcpyDeviceToHost, st));
+  FW_HIP(hipStreamSynchronize(st));
   int cb = 0;   // first chunk of the request inside the run
   for (GenRequest* r : reqs) {
     for (int b = 0; b < r->B; ++b) {

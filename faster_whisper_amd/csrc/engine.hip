@@ -1084,25 +1084,22 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   return gen_workspace_ensure(m);
 }
 
-// CU mask of n CUs spread evenly over the 8 XCDs.  Whether bit i of a HIP CU mask is CU (i % 32) of XCD (i / 32)
-// or CU (i / 8) of XCD (i % 8) is not documented; this pattern selects 4k + j CUs of every XCD under either
-// reading (n = 32k + 8j): key = (i%8 + i/8) % 8 < k picks k of every 8 in both, the partial class is split by
-// ((i/8)%4 + i/64) % 4 < j which runs over all four values inside an XCD in both.
+// CU mask of n = 32k CUs, 4k in every XCD.  Whether bit i of a HIP CU mask is CU (i % 32) of XCD (i / 32) or CU
+// (i / 8) of XCD (i % 8) is not documented; (i%8 + i/8) % 8 < k selects k of every 8 consecutive CUs of an XCD under
+// either reading.  (A finer, 8-CU granularity was tried with a second balanced split of the partial class; the
+// encoder GEMM — whose tile -> XCD mapping assumes equal XCDs — ran 45 % slower at 112 CUs than at 96.)
 static void balanced_cu_mask(int n_cus, uint32_t mask[8]) {
-  const int k = n_cus / 32, j = (n_cus % 32) / 8;
+  const int k = n_cus / 32;
   for (int w = 0; w < 8; ++w) mask[w] = 0;
-  for (int i = 0; i < 256; ++i) {
-    const int a = i % 8, b = i / 8;
-    const int key = (a + b) % 8;
-    if (key < k || (key == k && ((b % 4) + (b / 8)) % 4 < j)) mask[i >> 5] |= 1u << (i & 31);
-  }
+  for (int i = 0; i < 256; ++i)
+    if (((i % 8) + (i / 8)) % 8 < k) mask[i >> 5] |= 1u << (i & 31);
 }
 
 int32_t fw_model_set_encoder_cus(fw_model* fm, int32_t n_cus) {
   FW_CHECK_ARG(fm, "null model");
   Model* m = &fm->impl;
-  FW_CHECK_ARG(n_cus == 0 || (n_cus >= 32 && n_cus <= 256 && n_cus % 8 == 0),
-               "encoder CUs: 0 (all) or a multiple of 8 in [32, 256]");
+  FW_CHECK_ARG(n_cus == 0 || (n_cus >= 32 && n_cus <= 256 && n_cus % 32 == 0),
+               "encoder CUs: 0 (all) or a multiple of 32 in [32, 256]");
   FW_HIP(hipSetDevice(m->device));
   hipStream_t fresh = nullptr;
   if (n_cus == 0 || n_cus == 256) {
@@ -1667,6 +1664,55 @@ int32_t fw_test_dec_logits(fw_model* fm, const float* x, int32_t R, float* out) 
     set_error("logits projection test failed: %s", lr ? "unsupported shape" : hipGetErrorString(he));
     return FW_ERUNTIME;
   }
+  return FW_OK;
+}
+
+// Micro-benchmark of the decoder linear kernel's tile shapes (profiles/dec_linear_bench.py): `iters` back-to-back
+// launches on one stream over a ROTATING set of weight matrices larger than L2 + MALL (as in a decode step, where
+// 1.5 GB of weights pass between two uses of the same matrix); us_out = mean microseconds per launch.
+int32_t fw_bench_dec_linear(fw_model* fm, int32_t R, int32_t N, int32_t K, int32_t lnf, int32_t variant, int32_t iters,
+                            float* us_out) {
+  FW_CHECK_ARG(fm && us_out && R > 0 && N > 0 && K > 0 && iters > 0, "bad argument");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  const size_t wn = (size_t)N * K;
+  const int copies = (int)std::max<size_t>(2, ((size_t)640 << 20) / (wn * 2));
+  const size_t rp = ((size_t)R + 15) / 16 * 16;
+  half_t *dW = nullptr, *dX = nullptr, *dO = nullptr, *dB = nullptr;
+  float *dS = nullptr, *dC = nullptr;
+  int rc;
+  auto cleanup = [&]() { for (void* p : {(void*)dW, (void*)dX, (void*)dO, (void*)dB, (void*)dS, (void*)dC}) if (p) (void)hipFree(p); };
+  if ((rc = dev_alloc_t(&dW, wn * copies)) || (rc = dev_alloc_t(&dX, rp * K)) || (rc = dev_alloc_t(&dO, rp * N)) ||
+      (rc = dev_alloc_t(&dB, (size_t)N)) || (rc = dev_alloc_t(&dS, (size_t)N)) || (rc = dev_alloc_t(&dC, (size_t)N))) {
+    cleanup();
+    return rc;
+  }
+  FW_HIP(hipMemset(dW, 0x11, wn * copies * 2));
+  FW_HIP(hipMemset(dX, 0x22, rp * K * 2));
+  FW_HIP(hipMemset(dB, 0, (size_t)N * 2));
+  FW_HIP(hipMemset(dS, 0, (size_t)N * 4));
+  FW_HIP(hipMemset(dC, 0, (size_t)N * 4));
+  hipEvent_t e0, e1;
+  FW_HIP(hipEventCreate(&e0));
+  FW_HIP(hipEventCreate(&e1));
+  hipStream_t st = m->stream;
+  int lr = 0;
+  for (int i = 0; i < 4 && lr == 0; ++i)
+    lr = fwd::launch_dec_gemm_frag_variant(st, variant, lnf != 0, dX, dW + (size_t)(i % copies) * wn, dB, dS, dC, dO, R, N, K);
+  FW_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters && lr == 0; ++i)
+    lr = fwd::launch_dec_gemm_frag_variant(st, variant, lnf != 0, dX, dW + (size_t)(i % copies) * wn, dB, dS, dC, dO, R, N, K);
+  FW_HIP(hipEventRecord(e1, st));
+  hipError_t he = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  cleanup();
+  if (lr != 0) { set_error("fw_bench_dec_linear: unsupported shape / variant"); return FW_EINVAL; }
+  if (he != hipSuccess) { set_error("fw_bench_dec_linear: %s", hipGetErrorString(he)); return FW_ENODEV; }
+  *us_out = ms * 1000.f / (float)iters;
   return FW_OK;
 }
 

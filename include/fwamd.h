@@ -168,7 +168,7 @@ int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
 /* Compute-unit partition between the encoder and the decode group of a device.  The encoder GEMM is MFMA-bound and
  * holds a CU's whole register file and LDS; the decode step is HBM- and latency-bound and cannot co-reside with it.
  * Left alone the two time-slice the chip (wall = encoder + decode).  Confining the ENCODER stream of every replica
- * to n_cus CUs (a multiple of 8 in [32, 256], spread evenly over the XCDs; 0 = no confinement) leaves the other
+ * to n_cus CUs (a multiple of 32 in [32, 256], the same number in every XCD; 0 = no confinement) leaves the other
  * CUs to the decode run at all times, so the two overlap.  Recreates the model's encoder stream: call it after
  * fw_model_create and before the first encode, from one thread.  (No counterpart in the reference: CTranslate2
  * replicas share a GPU through the driver's time slicing, transcribe.py:645-657.) */
@@ -296,6 +296,11 @@ int32_t fw_test_logits_rules(fw_model* m, const float* logits, int32_t R, const 
  * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
 int32_t fw_bench_gemm(fw_model* m, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
                       int32_t trans, int32_t iters, float* ms_out);
+/* micro-benchmark of the decoder linear kernel (dec_gemm_frag_kernel) for a tile-shape `variant` (dec_kernels.hip:
+ * launch_dec_gemm_frag_variant; 0 / 1 = the product's) over a rotating weight set larger than the caches:
+ * mean microseconds per launch of a [R] x [N][K] linear (lnf = LayerNorm-folded form). */
+int32_t fw_bench_dec_linear(fw_model* m, int32_t R, int32_t N, int32_t K, int32_t lnf, int32_t variant, int32_t iters,
+                            float* us_out);
 int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const float* b,
                           int32_t rows, int32_t d, float* out);
 int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,

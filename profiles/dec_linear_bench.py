@@ -1,0 +1,35 @@
+"""Tile-shape micro-benchmark of the decoder linear kernel (fw_bench_dec_linear): microseconds per launch for the
+large-v3 decode-step shapes at the row counts of solo (80) and merged (320, 640) decode runs.
+    python profiles/dec_linear_bench.py > gpurun_out/dec_linear_bench.txt"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # noqa: E402
+
+VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)", 2: "8w 4x2 ch3", 3: "8w 4x2 ch4",
+            4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2"}
+SHAPES = [("qkv", 3840, 1280, 1), ("dxd", 1280, 1280, 0), ("ffn1", 5120, 1280, 1), ("ffn2", 1280, 5120, 0)]
+
+
+def main():
+    cfg = get_config("micro")
+    m = Whisper("synthetic:micro", device="cuda", files={"config": cfg, "weights": synthetic_weights(cfg, seed=1)},
+                max_batch_size=1, max_beam_size=1)
+    h = m._replicas[0].handle
+    us = C.c_float()
+    rows = [int(a) for a in sys.argv[1:]] or [80, 320, 640]
+    for R in rows:
+        print(f"R = {R}")
+        print("  %-30s" % "variant" + "".join("%10s" % s[0] for s in SHAPES) + "   layer (qkv + 3 dxd + ffn1 + ffn2)")
+        for v, name in VARIANTS.items():
+            t = []
+            for _, N, K, lnf in SHAPES:
+                _lib.check(m._lib.fw_bench_dec_linear(h, R, N, K, lnf, v, 400, C.byref(us)))
+                t.append(us.value)
+            print("  %-30s" % name + "".join("%10.2f" % x for x in t) + "   %8.1f" % (t[0] + 3 * t[1] + t[2] + t[3]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -145,12 +145,12 @@ def test_encoder_cu_partition_changes_nothing_but_the_schedule():
     common = dict(device="cuda", files={"config": cfg, "weights": w}, max_batch_size=3, max_beam_size=5,
                   inter_threads=2)
     free = Whisper("synthetic:tiny.en", encoder_cus=0, **common)
-    part = Whisper("synthetic:tiny.en", encoder_cus=104, **common)
+    part = Whisper("synthetic:tiny.en", encoder_cus=96, **common)
     lib = part._lib
-    assert [lib.fw_model_encoder_cus(r.handle) for r in part._replicas] == [104, 104]
+    assert [lib.fw_model_encoder_cus(r.handle) for r in part._replicas] == [96, 96]
     assert [lib.fw_model_encoder_cus(r.handle) for r in free._replicas] == [0, 0]
-    assert lib.fw_model_set_encoder_cus(part._replicas[0].handle, 100) != 0      # not a multiple of 8: rejected
-    assert lib.fw_model_encoder_cus(part._replicas[0].handle) == 104
+    assert lib.fw_model_set_encoder_cus(part._replicas[0].handle, 100) != 0      # not a multiple of 32: rejected
+    assert lib.fw_model_encoder_cus(part._replicas[0].handle) == 96
     prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
     kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True)
     for b in _batches(2, 3):

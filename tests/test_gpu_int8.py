@@ -112,6 +112,7 @@ def setup(request):
     from oracle.whisper import OracleWhisper
     cfg, w, model = make_model(request.param, seed=11, max_batch=4, max_beam=5, compute_type="int8_float16")
     oracle = OracleWhisper(cfg, w, int8=True)
+    model._test_weights = w
     chunks = [bench_audio(480000, seed=1), bench_audio(200000, seed=2), bench_audio(480000, seed=3)[::-1].copy()]
     feats = model.log_mel(chunks)
     return cfg, model, oracle, feats
@@ -126,6 +127,31 @@ def _prompt(cfg, timestamps=False):
 
 def _suppress(cfg):
     return sorted({cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe, 1, 2, 7})
+
+
+@pytest.mark.parametrize("R", [3, 15, 80, 83])
+def test_dec_logits_int8(setup, R):
+    """the int8 vocabulary projection of a decode step on the model's own (quantised) embedding: final LayerNorm ->
+    per-row int8 -> v_mfma_i32_16x16x64_i8 over the whole vocabulary -> float32 logits, against the integer
+    reference column by column (a wrong scale or a misplaced column tile shows as an O(1) error in its columns; a
+    LayerNorm value that lands on the other side of a rounding boundary moves a logit by < 1 % of the row's range)"""
+    from faster_whisper_amd import _lib
+    cfg, model, oracle, _ = setup
+    w = model._test_weights
+    rng = np.random.default_rng(100 + R)
+    x = _h((rng.standard_normal((R, cfg.d_model)) * 2 + 0.5).astype(np.float32))
+    out = np.empty((R, cfg.n_vocab), np.float32)
+    _lib.check(model._lib.fw_test_dec_logits(model._replicas[0].handle, _lib.ptr(x), R, _lib.ptr(out)))
+    g, b = _h(w["dec.ln.g"].astype(np.float32)), _h(w["dec.ln.b"].astype(np.float32))
+    mu = x.mean(-1, keepdims=True)
+    xn = (x - mu) / np.sqrt(((x - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * g + b
+    xq, x_s = _quant_rows(xn.astype(np.float32))
+    wq, w_s = _quant_rows(_h(w["dec.tok_emb"].astype(np.float32)))
+    ref = (xq @ wq.T).astype(np.float32) * x_s[:, None] * w_s[None, :]
+    scale = np.abs(ref).max()
+    col_err = np.abs(out - ref).max(axis=0) / scale
+    print(f"[{cfg.name}] int8 logits R={R}: worst column {int(col_err.argmax())} rel err {col_err.max():.2e}")
+    assert np.isfinite(out).all() and col_err.max() < 1e-2
 
 
 def test_compute_type_reported(setup):
