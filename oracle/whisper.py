@@ -52,8 +52,9 @@ class GenResult:
     sequences_ids: List[List[int]]
     scores: List[float]
     no_speech_prob: float
-    # diagnostics for margin-aware parity checks: per generated step of the best hypothesis,
-    # (top1 - top2) of the processed log-probs along the greedy path (beam_size == 1 only)
+    # diagnostics for margin-aware parity checks.  beam_size == 1: per generated step, (top1 - top2) of the processed
+    # log-probs along the greedy path.  beam search: per step, the gap between candidates K and K + 1 of
+    # cum + logp (the pruning boundary)
     margins: List[float] = field(default_factory=list)
 
 
@@ -403,6 +404,7 @@ class OracleWhisper:
         beams = [[] for _ in range(K)]          # generated tokens per live beam
         cum = np.zeros(K, dtype=np.float32)
         finished = []                           # (score, tokens, cum)
+        beam_gaps = []
         n_live_src = 1                          # first step expands from beam 0 only
         V = c.n_vocab
         step = 0
@@ -412,6 +414,10 @@ class OracleWhisper:
             lp = np.stack([proc(logits[k], beams[k]) for k in range(n_live_src)])
             flat = (cum[:n_live_src, None] + lp).reshape(-1)
             order = _topk_stable(flat, 2 * K)
+            # pruning-boundary gap of this step (candidate K vs K + 1): an engine whose scores carry noise of that
+            # size may legitimately keep a different beam set from here on (tests: conftest.check_hypothesis)
+            if len(order) > K and np.isfinite(flat[order[K]]):
+                beam_gaps.append(float(flat[order[K - 1]] - flat[order[K]]))
             last_step = (step + 1) >= budget
             new_beams, new_cum, parents, new_tok = [], [], [], []
             sec = K                              # secondary candidate cursor
@@ -450,7 +456,7 @@ class OracleWhisper:
             n_live_src = K
         finished.sort(key=lambda t: -t[0])      # stable: earlier-finished first among equal scores
         best = finished[:max(1, num_hyp)]
-        return GenResult([t[1] for t in best], [float(t[0]) for t in best], no_speech)
+        return GenResult([t[1] for t in best], [float(t[0]) for t in best], no_speech, margins=beam_gaps)
 
     def _greedy(self, cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced, sample=None):
         c = self.cfg

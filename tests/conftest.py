@@ -93,7 +93,7 @@ def forced_score(oracle, enc_np_b, prompt, ids, kw):
     return r.scores[0]
 
 
-def check_hypothesis(oracle, enc_np_b, prompt, got, ref, kw, tol=1e-3, gap=2e-2, what="", search=True):
+def check_hypothesis(oracle, enc_np_b, prompt, got, ref, kw, tol=1e-3, gap=2e-2, what="", search=True, boundary=0.0):
     """Parity criterion for one chunk of a beam-search (or greedy) result — never skipped, never "most of the time":
       1. the engine's reported score equals the ORACLE's score of the engine's own token sequence within `tol`
          (relative to max(1, |score|): the north-star 1e-3 on log-probs), whatever the search path was;
@@ -105,6 +105,11 @@ def check_hypothesis(oracle, enc_np_b, prompt, got, ref, kw, tol=1e-3, gap=2e-2,
     made; the engine's own score then has to satisfy check 2.
     search=False (greedy): after a tied step greedy decoding just follows another path, better or worse, so check 2
     does not apply — the caller checks the margin-safe prefix of the ids instead.
+    boundary: the same idea for beam search.  The oracle reports, per step, the gap between candidates K and K + 1
+    (the pruning boundary, GenResult.margins).  If the engine's scores carry noise of size `boundary` (int8
+    activations: a few 1e-2) and some step's gap is smaller, the two searches may keep different beam SETS from there
+    on and end arbitrarily far apart — that is the heuristic, not a defect — so check 2 is made only when every
+    boundary gap exceeds `boundary` (check 1 is made always).
     Returns True when the ids are identical."""
     ids = got.sequences_ids[0]
     s_forced = forced_score(oracle, enc_np_b, prompt, ids, kw)
@@ -118,5 +123,10 @@ def check_hypothesis(oracle, enc_np_b, prompt, got, ref, kw, tol=1e-3, gap=2e-2,
         assert not same, (what, "the oracle scores its own sequence -inf")
         s_forced = s_got
     if not same and search:
-        assert s_forced > s_ref - gap * max(1.0, abs(s_ref)), (what, ids, ref.sequences_ids[0], s_forced, s_ref)
+        tight = [g for g in (ref.margins or []) if g < boundary]
+        if tight:
+            print(f"{what}: {len(tight)} pruning-boundary gap(s) below {boundary:g} (smallest {min(tight):.4f}): "
+                  "the beam sets may differ, hypotheses not compared")
+        else:
+            assert s_forced > s_ref - gap * max(1.0, abs(s_ref)), (what, ids, ref.sequences_ids[0], s_forced, s_ref)
     return same

@@ -117,6 +117,7 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=6):
     for j, b in enumerate(SUBSET):
         try:
             check_hypothesis(oracle, sub[j], prompt, g5[b], r5[j], kw, tol=tol["beam"], gap=tol["gap"],
+                             boundary=2 * tol["beam"],
                              what=f"{tag} beam 5 chunk {b}")
         except AssertionError as e:
             expect(False, f"beam chunk {b}: {e}")

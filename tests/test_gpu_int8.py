@@ -11,7 +11,12 @@ from conftest import bench_audio, check_hypothesis, make_model
 
 pytestmark = pytest.mark.gpu
 
-MARGIN = 4e-2
+# Greedy ids are compared where the oracle's top-1 / top-2 margin exceeds MARGIN; beam hypotheses where every
+# pruning-boundary gap exceeds it.  Measured on tiny.en (profiles/diag_int8.py): the engine's and the oracle's int8
+# log-probs of a 2-token sequence differ by up to 3.5e-2 (the oracle quantises LayerNorm outputs rounded to fp16, the
+# engine the unrounded ones; ~2 % of the int8 codes land on the other side of a rounding boundary), which moved the
+# difference between two candidates by 4.7e-2.
+MARGIN = 8e-2
 
 
 def _h(x):
@@ -205,7 +210,7 @@ def test_generate_int8(setup, beam):
             assert g.sequences_ids[0][:n] == r.sequences_ids[0][:n]
         # score of the engine's own ids under the oracle always within 5e-3 (a flipped int8 code is visible);
         # different ids only when the two hypotheses are tied within 4e-2 under the oracle's scoring
-        check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, tol=5e-3, gap=4e-2, search=beam > 1,
+        check_hypothesis(oracle, enc_np[b], prompt, g, r, kw, tol=5e-3, gap=4e-2, search=beam > 1, boundary=MARGIN,
                          what=f"[{cfg.name}] int8 beam={beam} chunk {b}")
         assert abs(g.no_speech_prob - r.no_speech_prob) < 2e-3
 
