@@ -389,6 +389,7 @@ def single_utterance(model, cfg, chunk, prompt, kw, L, reps=3):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+PMC_FETCH_FILE = "r02_pmc_fetch.json"     # the round's counter pass (profiles/collect.sh r02)
 _PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "gemm_f16", "enc_attn": "attn_enc_kernel",
                "dec_gemm": "dec_gemm_frag_kernel", "dec_self_attn": "dec_self_attn_kernel",
                "dec_logits": "dec_gemm_wave_kernel"}
@@ -399,7 +400,9 @@ def pmc_traffic(family):
     (profiles/rNN_pmc_fetch*.json, x2 gfx950 correction already applied by profiles/parse_pmc.py); null if that
     kernel was not measured."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch*.json")))
+    files = [os.path.join(ROOT, "profiles", PMC_FETCH_FILE)]
+    if not os.path.exists(files[0]):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch*.json")))
     if not files or family not in _PMC_KERNEL:
         return None
     path = files[-1]
@@ -415,7 +418,8 @@ def pmc_traffic(family):
     if n == 0:
         return None
     return {"hbm_read_bytes_per_launch": round(tot / n), "source": os.path.relpath(path, ROOT),
-            "note": "that pass profiles one batch at a time (16 chunks per decode run)"}
+            "note": "mean over the launches of that kernel in the counter pass (profiles/collect.sh: the same "
+                    "bench command, 8 workers, merged decode runs, eager decode step)"}
 
 
 def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
