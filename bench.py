@@ -148,7 +148,7 @@ def build_backend(args, cfg, rank, world, local_rank):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--encoder-cus", type=int, default=None,
@@ -156,9 +156,11 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=100)
-    ap.add_argument("--workers", type=int, default=8,
+    ap.add_argument("--workers", type=int, default=32,
                     help="host threads submitting batches per GPU (worker replicas: own encoder stream, shared "
-                         "weights, shared decode group)")
+                         "weights, shared decode group).  The merged decode run grows with the batches in flight "
+                         "and every decoder weight is streamed once per run: measured 6: 2 221x, 8: 2 405x, 12: 2 523x, "
+                         "16: 2 595x, 20: 2 740x, 24: 2 765x, 32: 2 834x (decode workspace clamped to 336 chunks by HBM)")
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
                     help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
     ap.add_argument("--word-timestamps", action="store_true",
@@ -417,9 +419,13 @@ def pmc_traffic(family):
             n += d
     if n == 0:
         return None
-    return {"hbm_read_bytes_per_launch": round(tot / n), "source": os.path.relpath(path, ROOT),
-            "note": "mean over the launches of that kernel in the counter pass (profiles/collect.sh: the same "
-                    "bench command, 8 workers, merged decode runs, eager decode step)"}
+    out = {"hbm_read_bytes_per_launch": round(tot / n), "source": os.path.relpath(path, ROOT),
+           "note": "mean over the launches of that kernel in the counter pass (profiles/collect.sh: the same bench "
+                   "command with --workers 1, i.e. one 16-chunk batch per decode run, eager decode step)"}
+    if family == "dec_cross_attn":
+        # one launch = one decoder layer for the chunks of the run: K and V^T of that layer, 1500 x 1280 fp16 each
+        out["algorithmic_bytes_per_launch_in_that_pass"] = 16 * 2 * 1500 * 1280 * 2
+    return out
 
 
 def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):

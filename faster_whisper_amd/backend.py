@@ -25,7 +25,8 @@ from . import _lib
 from .config import WhisperConfig, get_config
 from .weights import synthetic_weights, weight_shapes
 
-# CUs the encoder streams of a multi-worker device are confined to (0 = no confinement); see Whisper.__init__
+# CUs the encoder streams of a multi-worker device are confined to (0 = no confinement: measured best on the
+# benchmark workload); Whisper(..., encoder_cus=n) overrides
 ENCODER_CUS_DEFAULT = 0
 
 _COMPUTE_TYPES = {
@@ -260,8 +261,7 @@ class Whisper:
         decode_group = bool(kwargs.pop("decode_group", True))
         encoder_cus = kwargs.pop("encoder_cus", None)
         if encoder_cus is None:
-            encoder_cus = int(os.environ.get("FWAMD_ENCODER_CUS", ENCODER_CUS_DEFAULT)) \
-                if (decode_group and inter_threads > 1) else 0
+            encoder_cus = ENCODER_CUS_DEFAULT if (decode_group and inter_threads > 1) else 0
         self._encoder_cus = int(encoder_cus)
         for i in idx:
             primary = _Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev)

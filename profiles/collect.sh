@@ -6,9 +6,9 @@
 # Writes under gpurun_out/<tag>/ and copies what is to be judged into profiles/<tag>_*:
 #   bench.json                  python bench.py (the bench line: roofline + cpu_baseline + secondary measurements)
 #   kernel_stats_w1.csv         rocprofv3 --kernel-trace --stats, ONE batch at a time (16-chunk decode runs), eager decode
-#   kernel_stats_w8.csv         the same with 8 workers: merged decode runs next to the encoders (durations of concurrent
-#                               kernels overlap in this one: read it for the decode stream, not for the encoders)
-#   pmc_fetch.json              FETCH_SIZE per kernel (x2 gfx950 correction applied by parse_pmc.py), 8 workers
+#   kernel_stats_w32.csv        the same with the bench's 32 workers: merged decode runs next to the encoders (durations
+#                               of concurrent kernels overlap in this one: read it for the decode stream)
+#   pmc_fetch.json              FETCH_SIZE per kernel (x2 gfx950 correction applied by parse_pmc.py), one batch at a time
 #   pmc_sq.json                 SQ wait / active / MFMA-busy / LDS-conflict counters per kernel, one batch at a time
 # Counter passes are separate runs with --pmc only (gpurun refuses --pmc combined with the trace domains).
 # The decode step runs eagerly under the profiler (FWAMD_NO_GRAPH=1): rocprofv3 7.2 crashes on replayed hipGraphs.
@@ -20,12 +20,12 @@ mkdir -p "$OUT"
 export FWAMD_BLOB_CACHE=/tmp/fwamd_blob
 Q="--no-cpu-baseline --no-profile-pass --no-secondary"
 cd "$R"
-timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-400 "$OUT/bench.json"
+timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-400 "$OUT/bench.json"
 cp "$OUT/bench.json" "$R/profiles/${TAG}_bench.json"
 cd /tmp; export TMPDIR=/tmp
 trace() {   # name, bench args...
   local name=$1; shift
-  FWAMD_NO_GRAPH=1 timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -o kt -- \
+  FWAMD_NO_GRAPH=1 timeout 330 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -o kt -- \
       python "$R/bench.py" $Q "$@" > "$OUT/prof_$name.log" 2>&1
   local f; f=$(find "$OUT/prof_$name" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$name.csv" && cp "$f" "$R/profiles/${TAG}_kernel_stats_$name.csv"
@@ -42,7 +42,9 @@ pmc() {     # name, bench args ... -- counters...
   rm -rf "$OUT/prof_$name"
 }
 trace w1 --workers 1 --steps 2 --warmup 1
-trace w8 --steps 8 --warmup 1
-pmc fetch --steps 8 --warmup 1 -- FETCH_SIZE
+trace w32 --steps 32 --warmup 1
+pmc fetch --workers 1 --steps 2 --warmup 1 -- FETCH_SIZE
 pmc sq --workers 1 --steps 1 --warmup 1 -- SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 head -12 "$OUT/kernel_stats_w1.csv" | cut -c1-150
+head -8 "$OUT/kernel_stats_w32.csv" | cut -c1-150
+ls -la "$OUT"
