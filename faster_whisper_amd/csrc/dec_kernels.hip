@@ -53,19 +53,21 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
 // one contiguous 1 KB run, operands go straight from L2/HBM to VGPRs: no LDS staging, no DMA ring, no
 // barriers in the K loop, so a workgroup holds no LDS while it waits on memory (the LDS-staged form above is
 // latency-bound single stream AND LDS-residency-bound with several batches in flight).
-//   * one workgroup = one 16-column tile x one 16-row tile; its WAVES waves split K and issue ALL their
-//     loads at once (10 k-steps = 20 x 16 B per lane): one memory latency per launch for K <= 1280;
-//   * grid (N/16, row tiles): the row tiles of a column tile land on the same XCD (N/16 is a multiple of 8),
-//     so a weight tile is fetched from HBM once and re-read from that XCD's L2;
-//   * fixed-order reduction of the WAVES partial tiles through 4 KB of LDS, epilogue by wave 0.
+//   * one workgroup = RT x NT tiles of 16 x 16 (2 x 2 in the product: the x / W fragments of a k-step are re-used
+//     for 4 MFMAs); its WAVES waves split K and keep CH k-steps of loads in flight each ((RT + NT) * CH * 16 B per
+//     lane): two load rounds per launch for K <= 1280;
+//   * grid (N/16/NT, row groups): the row groups of a column group land on the same XCD (the grid's x extent is a
+//     multiple of 8), so a weight tile is fetched from HBM once and re-read from that XCD's L2 — with merged decode
+//     runs (320-1 680 rows) that L2 traffic, not HBM, is what bounds the kernel (profiles/NOTES.md);
+//   * fixed-order reduction of the WAVES partial tiles through LDS, epilogue spread over the waves.
 // ------------------------------------------------------------------------------------
 template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
     half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
-  // RT x NT tiles of 16 x 16 per workgroup (1 x 1 by default; larger tiles re-use the x / W fragments in
-  // registers and cut the L2 re-reads at the price of fewer workgroups — experiment knobs, see the launcher)
+  // RT x NT tiles of 16 x 16 per workgroup (larger tiles re-use the x / W fragments in registers and cut the L2
+  // re-reads at the price of fewer, fatter workgroups: launch_dec_gemm_frag_variant / profiles/dec_linear_bench.py)
   __shared__ float red[WAVES][RT * NT][64][4];
   __shared__ float red_s[WAVES][RT][16][2];
   constexpr int CH = CH_ ? CH_ : 20 / (RT + NT);   // k-steps in flight per wave: (RT + NT) * CH * 16 B per lane
@@ -184,8 +186,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// int8 form of the fragment-major skinny GEMM (int8_float16; experiment, FWAMD_DEC_GEMM_I8=frag at pack time —
-// written after round 1's GPU budget was spent: compiles, not yet run).  Same structure as
+// int8 form of the fragment-major skinny GEMM (compute_type int8_float16).  Same structure as
 // dec_gemm_frag_kernel with v_mfma_i32_16x16x64_i8: a 16-byte fragment holds 16 int8 (k-step = 64), weights are
 // permuted at pack time, activations are written fragment-major by quant_rows_kernel(frag = 1); the epilogue
 // de-quantises with the per-row activation scale and the per-row weight scale.  Output fp16 row-major.
