@@ -56,9 +56,9 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
 //   * one workgroup = RT x NT tiles of 16 x 16 (2 x 2 in the product: the x / W fragments of a k-step are re-used
 //     for 4 MFMAs); its WAVES waves split K and keep CH k-steps of loads in flight each ((RT + NT) * CH * 16 B per
 //     lane): two load rounds per launch for K <= 1280;
-//   * 1-D grid ordered so that the row groups of a column group run back to back on one XCD: a weight tile is
-//     fetched from HBM once and re-read from that XCD's L2 — with merged decode runs (320-1 680 rows) that L2
-//     traffic, not HBM, is what bounds the kernel (profiles/NOTES.md);
+//   * grid (N/16/NT, row groups): the row groups of a column group land on the same XCD (the grid's x extent is a
+//     multiple of 8), so a weight tile is fetched from HBM once and re-read from that XCD's L2 — with merged decode
+//     runs (320-1 680 rows) that L2 traffic, not HBM, is what bounds the kernel (profiles/NOTES.md);
 //   * fixed-order reduction of the WAVES partial tiles through LDS, epilogue spread over the waves.
 // ------------------------------------------------------------------------------------
 template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0>
@@ -74,14 +74,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  // 1-D grid: blocks 8k .. 8k+7 are eight column groups of ONE row group, the next eight blocks the same column
-  // groups of the next row group (the hardware places block b on XCD b % 8): the row groups that stream the same
-  // weight columns run back to back on the same XCD, so all but the first find them in its L2
+  const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
   const int n_rt = (R + 15) >> 4;
-  const int n_rg = (n_rt + RT - 1) / RT;
-  const int b8 = blockIdx.x >> 3;
-  const int ct0 = ((b8 / n_rg) * 8 + (blockIdx.x & 7)) * NT, rt0 = (b8 % n_rg) * RT;
-  if (ct0 * 16 >= N) return;   // column groups are padded to a multiple of 8 (whole workgroup leaves: no barrier yet)
   const int KS = K >> 5;
   const int per = (KS + WAVES - 1) / WAVES;
   const int ks0 = wave * per;
@@ -207,14 +201,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_i8_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  // 1-D grid: blocks 8k .. 8k+7 are eight column groups of ONE row group, the next eight blocks the same column
-  // groups of the next row group (the hardware places block b on XCD b % 8): the row groups that stream the same
-  // weight columns run back to back on the same XCD, so all but the first find them in its L2
+  const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
   const int n_rt = (R + 15) >> 4;
-  const int n_rg = (n_rt + RT - 1) / RT;
-  const int b8 = blockIdx.x >> 3;
-  const int ct0 = ((b8 / n_rg) * 8 + (blockIdx.x & 7)) * NT, rt0 = (b8 % n_rg) * RT;
-  if (ct0 * 16 >= N) return;   // column groups are padded to a multiple of 8 (whole workgroup leaves: no barrier yet)
   const int KS = K >> 6;
   const int per = (KS + WAVES - 1) / WAVES;
   const int ks0 = wave * per;
@@ -1143,7 +1131,7 @@ template <bool LNF, int RT, int NT>
 static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N,
                     int K, int act) {
-  const int grid = ((N / 16 / NT + 7) & ~7) * (((R + 15) / 16 + RT - 1) / RT);   // see the kernel's block mapping
+  const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
   if (waves == 8)
     dec_gemm_frag_kernel<8, LNF, RT, NT><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N,
                                                                K, act);
@@ -1156,7 +1144,7 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
 template <int WAVES, int RT, int NT, int CH>
 static void frag_variant(hipStream_t st, bool lnf, const half_t* xf, const half_t* Wf, const half_t* bias,
                          const float* s1, const float* cf, half_t* out, int R, int N, int K) {
-  const int grid = ((N / 16 / NT + 7) & ~7) * (((R + 15) / 16 + RT - 1) / RT);   // see the kernel's block mapping
+  const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
   if (lnf)
     dec_gemm_frag_kernel<WAVES, true, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, s1, cf, nullptr, 0, out, N,
                                                                               nullptr, R, N, K, 0);
@@ -1205,7 +1193,7 @@ int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_sca
                             const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
                             int R, int N, int K, int act) {
   if (K % 64 != 0 || N % 32 != 0 || R < 1 || !x_scale || !w_scale) return -1;
-  const int grid = ((N / 32 + 7) & ~7) * (((R + 15) / 16 + 1) / 2);   // see the kernel's block mapping
+  const dim3 grid(N / 32, ((R + 15) / 16 + 1) / 2);
   if (K >= 2560)
     dec_gemm_frag_i8_kernel<8, 2, 2><<<grid, 512, 0, st>>>(xq, x_scale, Wq, w_scale, bias, res, ldr, out, ldo, R, N, K, act);
   else
