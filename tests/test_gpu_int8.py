@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 
 # Greedy ids are compared where the oracle's top-1 / top-2 margin exceeds MARGIN; beam hypotheses where every
 # pruning-boundary gap exceeds it.  Measured on tiny.en (profiles/diag_int8.py): the engine's and the oracle's int8
-# log-probs of a 2-token sequence differ by up to 3.5e-2 (the oracle quantises LayerNorm outputs rounded to fp16, the
-# engine the unrounded ones; ~2 % of the int8 codes land on the other side of a rounding boundary), which moved the
-# difference between two candidates by 4.7e-2.
+# log-probs of a 2-token sequence differ by up to 3.5e-2, the difference between two candidates by 4.7e-2.  Both
+# sides quantise fp16 values with scale = absmax / 127; when the two absmax elements of a row are one fp16 ulp apart
+# (accumulation order), the scales differ by 1e-3 and every element within 0.13 * |x| / absmax of a rounding boundary
+# — several per cent of the row — lands on the neighbouring code.
 MARGIN = 8e-2
 
 
