@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # log-probs of a 2-token sequence differ by up to 3.5e-2, the difference between two candidates by 4.7e-2.  Both
 # sides quantise fp16 values with scale = absmax / 127; when the two absmax elements of a row are one fp16 ulp apart
 # (accumulation order), the scales differ by 1e-3 and every element within 0.13 * |x| / absmax of a rounding boundary
-# — several per cent of the row — lands on the neighbouring code.
+# — about 2 % of the row, up to 5 % — lands on the neighbouring code.
 MARGIN = 8e-2
 
 
