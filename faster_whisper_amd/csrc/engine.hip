@@ -1535,7 +1535,7 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
   if ((rc = dev_alloc_t(&d_of, (size_t)R16 * N))) { cleanup(); return rc; }
   owned.push_back(d_of);
   FW_HIP(hipMemset(d_of, 0, (size_t)R16 * N * 2));
-  if (use_int8) {
+  if (use_int8 == 1) {
     if (m->compute_type != FW_COMPUTE_INT8_FLOAT16 || ln_g) {
       cleanup();
       set_error("int8 decoder-linear test needs an int8_float16 model and no LayerNorm");
@@ -1612,7 +1612,16 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
     for (int n = 0; n < N; ++n) tmp[n] = f32_to_f16_bits(bias[n]);
     if ((rc = up(tmp.data(), (size_t)N * 2, (void**)&d_bias))) { cleanup(); return rc; }
   }
-  if (fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act) != 0) {
+  // use_int8 == 2: the GEMM-shaped candidate for merged runs (dec_gemm_tile_kernel), same operands
+  // (use_int8 == 3 / 4: its 3- / 4-stage form)
+  const int lr =
+      use_int8 == 2 ? fwd::launch_dec_gemm_tile(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
+      : (use_int8 == 3 || use_int8 == 4)
+          ? fwd::launch_dec_gemm_tile_pipe(st, use_int8, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
+      : use_int8 == 5   // the skinny kernel whatever the row count (the reference of the bit-identity test)
+          ? fwd::launch_dec_gemm_skinny(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
+          : fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act);
+  if (lr != 0) {
     cleanup();
     set_error("decoder linear: unsupported shape R=%d N=%d K=%d", R, N, K);
     return FW_ERUNTIME;

@@ -276,7 +276,9 @@ int32_t fw_test_gemm(fw_model* m, const float* A, const float* W, const float* b
 /* one decoder linear exactly as a decode step runs it (fragment-major operands, LayerNorm folded when ln_g/ln_b are
  * given, GELU when act = 1, residual added last): x [R][K], W [N][K], bias [N] | NULL, res [R][N] | NULL ->
  * out [R][N] (row-major result) and out_from_frag [R][N] (the fragment-major copy the next linear reads, un-permuted
- * on the host).  use_int8: the int8_float16 form (needs an int8_float16 model; ln must be NULL). */
+ * on the host).  use_int8 = 0: what a decode step launches for this row count; 1: the int8_float16 form (needs an
+ * int8_float16 model; ln must be NULL); 2 / 3 / 4: the GEMM-shaped kernel of large merged runs (dec_gemm_tile_kernel,
+ * 2-, 3-, 4-stage forms) whatever the row count; 5: the skinny kernel whatever the row count.  0, 2-5 return the same bits. */
 int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const float* bias, const float* ln_g,
                            const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
                            int32_t use_int8, float* out, float* out_from_frag);

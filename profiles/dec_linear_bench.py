@@ -9,7 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # noqa: E402
 
 VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)", 2: "8w 4x2 ch3", 3: "8w 4x2 ch4",
-            4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2"}
+            4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2",
+            10: "LDS-shared 128x64 tile, 2 stages", 11: "LDS-shared 128x64 tile, 3 stages",
+            12: "LDS-shared 128x64 tile, 4 stages"}
+if os.environ.get("DLB_VARIANTS"):
+    VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["DLB_VARIANTS"].split(",")}
 SHAPES = [("qkv", 3840, 1280, 1), ("dxd", 1280, 1280, 0), ("ffn1", 5120, 1280, 1), ("ffn2", 1280, 5120, 0)]
 
 

@@ -199,6 +199,30 @@ def test_dec_linear_layernorm_folded_gelu(model, R, N, K):
         assert np.array_equal(out, out_frag)
 
 
+@pytest.mark.parametrize("R", [80, 333, 1680])
+def test_dec_linear_tile_bit_identical(model, R):
+    """the GEMM-shaped decoder linear for merged runs (dec_gemm_tile_kernel: operands staged once per 128 x 64
+    workgroup tile in LDS) must return EXACTLY the bits of the product's skinny kernel at every large-v3 step shape —
+    it keeps that kernel's K slices, MFMA chains and addition order — so that a merged decode run stays
+    bit-identical to a solo run whichever kernel serves it"""
+    rng = np.random.default_rng(900 + R)
+    for N, K, ln, act, use_res in ((1280, 1280, False, 0, True), (3840, 1280, True, 0, False),
+                                   (5120, 1280, True, 1, False), (1280, 5120, False, 0, True)):
+        x = _h((rng.standard_normal((R, K)) * 1.3 + 0.2).astype(np.float32))
+        W = _h((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        b = _h(0.1 * rng.standard_normal(N).astype(np.float32))
+        r = _h(rng.standard_normal((R, N)).astype(np.float32)) if use_res else None
+        lnp = (_h(1 + 0.1 * rng.standard_normal(K).astype(np.float32)),
+               _h(0.05 * rng.standard_normal(K).astype(np.float32))) if ln else None
+        a, a_frag = _dec_linear(model, x, W, bias=b, ln=lnp, res=r, act=act, int8=5)    # the skinny kernel
+        for variant in (0, 2, 3, 4):  # what a decode step launches at this row count; tile kernel: 2, 3, 4 stages
+            t, t_frag = _dec_linear(model, x, W, bias=b, ln=lnp, res=r, act=act, int8=variant)
+            same = np.array_equal(a, t)
+            print(f"tile[{variant}] vs skinny {R}x{N}x{K} ln={ln} act={act}: identical={same}, "
+                  f"max diff {np.abs(a - t).max():.2e}")
+            assert same and np.array_equal(a_frag, t_frag)
+
+
 @pytest.mark.parametrize("R", [1, 5, 16, 48, 64, 80, 83, 640])
 def test_dec_logits_projection(model, R):
     """the vocabulary projection of a decode step (full-K-per-wave kernel, final LayerNorm folded) against fp64 on
