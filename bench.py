@@ -325,7 +325,14 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             name, dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
             roof = roof_of(name, dom)
             roof["kernel"] = name
-            roof["traffic"] = pmc_traffic(name)
+            # `traffic` = HBM read bytes per launch from the PMC pass (a number, or null); the pass profiles one
+            # 16-chunk batch per launch, so `traffic_pass` carries the algorithmic bytes of a launch IN THAT PASS
+            tp = pmc_traffic(name)
+            roof["traffic"] = tp["hbm_read_bytes_per_launch"] if tp else None
+            roof["traffic_pass"] = tp
+            if tp and tp.get("algorithmic_bytes_per_launch_in_that_pass"):
+                roof["traffic_over_algorithmic"] = round(
+                    tp["hbm_read_bytes_per_launch"] / tp["algorithmic_bytes_per_launch_in_that_pass"], 4)
             roof["kernel_ms_per_step"] = round(dom["ms"], 3)
             roof["launch_groups_in_round"] = dom["launches"]
             roof["timing"] = (f"HIP events around every launch on the engine's streams, one round of {W} batches with "
@@ -338,7 +345,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                 if k in rep and k != name:
                     others[k] = rep[k]
             out["roofline_others"] = {
-                k: dict(roof_of(k, v), kernel_ms_per_step=round(v["ms"], 3), traffic=pmc_traffic(k))
+                k: dict(roof_of(k, v), kernel_ms_per_step=round(v["ms"], 3),
+                        traffic=(pmc_traffic(k) or {}).get("hbm_read_bytes_per_launch"))
                 for k, v in others.items() if v["ms"] > 0}
             if "dec_gemm" in out["roofline_others"]:
                 out["roofline_others"]["dec_gemm"]["note"] = (
