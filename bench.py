@@ -347,10 +347,11 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             out["roofline_others"] = {
                 k: dict(roof_of(k, v), kernel_ms_per_step=round(v["ms"], 3),
                         traffic=(pmc_traffic(k) or {}).get("hbm_read_bytes_per_launch"))
-                for k, v in others.items() if v["ms"] > 0}
+                for k, v in others.items()
+                if v["ms"] > 0 and (v["flops"] > 0 if k in MFMA_FAMILIES else v["bytes"] > 0)}
             if "dec_gemm" in out["roofline_others"]:
                 out["roofline_others"]["dec_gemm"]["note"] = (
-                    "weights are streamed once per decode run of up to 128 chunks (decode groups), so the algorithmic "
+                    "weights are streamed once per decode run of up to several hundred chunks (decode groups), so the algorithmic "
                     "bytes per launch are small: these launches are latency-bound, not bandwidth-bound")
             out["roofline"] = roof
             out["families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in rep.items()}
