@@ -60,12 +60,12 @@ class FwVadWeights(C.Structure):
     ]
 
 
-# every symbol include/fwamd.h declares (tests/test_abi.py checks the .so exports them all)
+# every symbol include/fwamd.h and include/fwamd_test.h declare (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [
     "fw_last_error", "fw_abi_version", "fw_device_count",
     "fw_model_create", "fw_model_free", "fw_model_info", "fw_model_blob", "fw_model_create_from_blob_dev",
     "fw_model_set_decode_batch", "fw_model_decode_batch", "fw_model_join_decoder", "fw_model_decode_stats",
-    "fw_model_set_encoder_cus", "fw_model_encoder_cus",
+    "fw_model_set_merge_wait",
     "fw_pack_blob_size", "fw_pack_blob_copy", "fw_pack_blob_free",
     "fw_logmel", "fw_logmel_full",
     "fw_encode", "fw_encode_pcm", "fw_encode_pcm_dev", "fw_tensor_shape", "fw_tensor_to_host",
@@ -109,10 +109,8 @@ def load():
     lib.fw_model_decode_batch.argtypes = [vp]
     lib.fw_model_decode_batch.restype = i32
     lib.fw_model_join_decoder.argtypes = [vp, vp]
+    lib.fw_model_set_merge_wait.argtypes = [vp, i32]
     lib.fw_model_decode_stats.argtypes = [vp, i64p, i64p, i64p, i32p]
-    lib.fw_model_set_encoder_cus.argtypes = [vp, i32]
-    lib.fw_model_encoder_cus.argtypes = [vp]
-    lib.fw_model_encoder_cus.restype = i32
     lib.fw_pack_blob_size.argtypes = [C.POINTER(FwConfig), C.POINTER(FwWeight), i32, i32, i64p, C.POINTER(vp)]
     lib.fw_pack_blob_copy.argtypes = [vp, vp, i64]
     lib.fw_pack_blob_free.argtypes = [vp]

@@ -25,10 +25,6 @@ from . import _lib
 from .config import WhisperConfig, get_config
 from .weights import synthetic_weights, weight_shapes
 
-# CUs the encoder streams of a multi-worker device are confined to (0 = no confinement: measured best on the
-# benchmark workload); Whisper(..., encoder_cus=n) overrides
-ENCODER_CUS_DEFAULT = 0
-
 _COMPUTE_TYPES = {
     "default": _lib.COMPUTE_FLOAT16, "auto": _lib.COMPUTE_FLOAT16, "float16": _lib.COMPUTE_FLOAT16,
     "int8_float16": _lib.COMPUTE_INT8_FLOAT16, "int8": _lib.COMPUTE_INT8_FLOAT16,
@@ -255,14 +251,11 @@ class Whisper:
         # The workers of a device form a DECODE GROUP (include/fwamd.h): they share one decode workspace sized
         # for all of their batches, and generate() calls that arrive concurrently are merged into one decode run
         # whose rows share every weight byte streamed per step.  decode_group=False keeps a decoder per worker.
-        # encoder_cus: with several workers the encoder streams are confined to that many CUs so that the decode
-        # run always has the rest of the chip (fwamd.h: fw_model_set_encoder_cus); None = the measured default
         self._replicas = []
         decode_group = bool(kwargs.pop("decode_group", True))
-        encoder_cus = kwargs.pop("encoder_cus", None)
-        if encoder_cus is None:
-            encoder_cus = ENCODER_CUS_DEFAULT if (decode_group and inter_threads > 1) else 0
-        self._encoder_cus = int(encoder_cus)
+        # merge_wait_ms: how long the leader of a decode run waits for workers that are still encoding
+        # (fwamd.h: fw_model_set_merge_wait; None = one encoder pass, 0 = never: lowest latency per call)
+        merge_wait_ms = kwargs.pop("merge_wait_ms", None)
         for i in idx:
             primary = _Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev)
             self._replicas.append(primary)
@@ -276,9 +269,8 @@ class Whisper:
                     if decode_group:
                         _lib.check(self._lib.fw_model_join_decoder(r.handle, primary.handle))
                     self._replicas.append(r)
-        if self._encoder_cus:
-            for r in self._replicas:
-                _lib.check(self._lib.fw_model_set_encoder_cus(r.handle, self._encoder_cus))
+            if merge_wait_ms is not None:
+                _lib.check(self._lib.fw_model_set_merge_wait(primary.handle, int(merge_wait_ms)))
         self._seed_counter = itertools.count(1)
         self._rr = itertools.count()
         self._tls = threading.local()

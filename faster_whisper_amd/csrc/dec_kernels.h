@@ -21,12 +21,14 @@ struct GenDev {
   float inv_temp;
   unsigned seed_lo, seed_hi;
   int kv_div;              // decode chunks per encoder chunk (sampling: num_hypotheses), 1 otherwise
+  int ctx, cache_rows;     // self-attention cache geometry of this run: positions per slot, slots per layer
 };
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d,
                   const int* d_step, int pos_fixed, int P);
-void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
+// n_ctx: stride of the slot table (the text context); cache_ctx: positions per slot of the K/V cache of this run
+void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int cache_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag);
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,

@@ -708,7 +708,8 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// K13: decoder self-attention, KV cache with slot indirection.  cache layout [slot][H][n_ctx][64].  The new K/V
+// K13: decoder self-attention, KV cache with slot indirection.  cache layout [slot][H][cache_ctx][64] (cache_ctx =
+// the positions the RUN can reach, <= n_ctx: the cache is sized per run, decoder.hip).  The new K/V
 // (position pos) are written to the row's own slot; older positions are read from kvidx[row][p] (slot inside the
 // chunk).  One workgroup = (head, chunk), one wave per beam row of the chunk: the beams of a chunk share most of
 // their history (kvidx points them at the same slots), so the rows a wave fetches are in the CU's L1 / the XCD's L2
@@ -717,8 +718,8 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
 // ------------------------------------------------------------------------------------
 #define SA_MAX_CTX 448
 __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
-                                                             half_t* __restrict__ vc, int n_ctx, int H,
-                                                             const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
+                                                             half_t* __restrict__ vc, int n_ctx, int cache_ctx,
+                                                             int H, const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
                                                              half_t* __restrict__ out, const int* __restrict__ d_step,
                                                              int pos_fixed, int P, int R_total, int frag) {
   extern __shared__ float sa_smem[];            // per wave: sp[n_ctx] floats, ssrc[n_ctx] ints
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const half_t* __res
   const int cur = (pos_fixed >= 0) ? 0 : (step & 1);
   const uint8_t* kvidx = kvidx2 + ((size_t)cur * R_total + slot) * n_ctx;
   const half_t* qr = qkv + (size_t)r * 3 * d + h * 64;
-  const size_t head_stride = (size_t)n_ctx * 64;
+  const size_t head_stride = (size_t)cache_ctx * 64;
   const size_t slot_stride = (size_t)H * head_stride;
   const int pg = lane >> 3, cc = lane & 7;     // position group, 16-byte chunk of the 128-byte row
   // this lane's 8 dims of q (scaled), k_new, v_new
@@ -1581,12 +1582,12 @@ int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_sc
   return 0;
 }
 
-void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int H,
+void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int cache_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag) {
   // one workgroup per (head, chunk), one wave per row of the chunk (kmul <= 16); LDS: scores + source slots per wave
   dec_self_attn_kernel<<<dim3(H, rows / kmul), kmul * 64, (size_t)kmul * 2 * n_ctx * sizeof(float), st>>>(
-      qkv, d, kc, vc, n_ctx, H, kvidx2, Kbeam, kmul, out, d_step, pos_fixed, P, R_total, frag);
+      qkv, d, kc, vc, n_ctx, cache_ctx, H, kvidx2, Kbeam, kmul, out, d_step, pos_fixed, P, R_total, frag);
 }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,

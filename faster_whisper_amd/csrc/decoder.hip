@@ -48,7 +48,12 @@ struct GenWorkspace {
   half_t *ck = nullptr, *cvt = nullptr;  // cross K / V^T [L][B][H][kvp*64], MFMA-fragment-major (dec_kernels.hip K14)
   std::vector<uint64_t> slot_enc;        // per chunk slot: id of the encoder output whose K/V it holds (0 = none)
   std::vector<int> slot_chunk;           //                 and which chunk of it
-  half_t *sk = nullptr, *sv = nullptr;   // [L][R][H][NT][64]
+  // self-attention cache: ONE allocation of L x self_cap x d halves per K and V, self_cap = R x NTs row-positions.
+  // Its geometry is the RUN's: [L][rows of the run][H][ctx of the run][64] with rows x ctx <= self_cap, so a run
+  // whose calls ask for max_length 104 holds 4.3x the rows of one that asks for the whole text context.
+  half_t *sk = nullptr, *sv = nullptr;
+  int NTs = 0;                           // positions per row at full row capacity
+  int64_t self_cap = 0;                  // rows x positions
   half_t *x = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
   float* logits = nullptr;               // [R][V]
   int* prompt_dev = nullptr;             // [NT][max(R, B)]
@@ -78,27 +83,37 @@ struct GenWorkspace {
 static std::atomic<uint64_t> g_tensor_id{1};
 uint64_t next_tensor_id() { return g_tensor_id.fetch_add(1); }
 
-int64_t gen_workspace_bytes(const Model* m, int decode_batch) {
+// positions per cache row at full row capacity: the whole text context when one encoder batch is all the workspace
+// holds, otherwise what set_decode_batch chose (>= the share that lets ONE full-context encoder batch run)
+static int self_positions(const Model* m, int decode_batch, int nts) {
+  const int NT = m->cfg.n_text_ctx;
+  const int need = (int)(((int64_t)NT * m->max_batch + decode_batch - 1) / decode_batch);   // EB*K*NT <= B*K*NTs
+  return std::min(NT, std::max(std::max(nts, need), 8));
+}
+
+int64_t gen_workspace_bytes(const Model* m, int decode_batch, int nts) {
   const fw_config& c = m->cfg;
   const int64_t B = decode_batch, R = B * m->max_beam, d = c.d_model, L = c.n_dec_layers, NT = c.n_text_ctx;
   const int64_t kvp = ((c.n_audio_ctx + 31) / 32) * 32;
-  int64_t n = 2 * (L * B * d * kvp) * 2 + 2 * (L * R * NT * d) * 2;   // cross K/V^T, self K/V (fp16)
+  const int64_t NTs = self_positions(m, decode_batch, nts > 0 ? nts : (int)NT);
+  int64_t n = 2 * (L * B * d * kvp) * 2 + 2 * (L * R * NTs * d) * 2;   // cross K/V^T, self K/V (fp16)
   n += R * (int64_t)c.n_vocab * 4 + R * 12 * d * 2 * 2;                // logits, activations
   n += R * FIN_CAP * NT * 4 + 3 * R * NT * 4;                          // finished hypotheses, histories
   return n + (64 << 20);
 }
 
-int gen_workspace_ensure(Model* m) {
-  if (m->gen) return FW_OK;
+static int gen_workspace_build(Model* m) {
   const fw_config& c = m->cfg;
   GenWorkspace* g = new GenWorkspace();
-  m->gen = g;
+  m->gen = g;   // gen_workspace_ensure frees it again when anything below fails
   if (m->decode_batch < m->max_batch) m->decode_batch = m->max_batch;
   g->B = m->decode_batch;
   g->EB = m->max_batch;
   g->K = m->max_beam;
   g->R = g->B * g->K;
   g->NT = c.n_text_ctx;
+  g->NTs = self_positions(m, m->decode_batch, m->decode_self_ctx > 0 ? m->decode_self_ctx : c.n_text_ctx);
+  g->self_cap = (int64_t)g->R * g->NTs;
   g->kvp = ((c.n_audio_ctx + 31) / 32) * 32;
   g->slot_enc.assign(g->B, 0);
   g->slot_chunk.assign(g->B, 0);
@@ -110,8 +125,8 @@ int gen_workspace_ensure(Model* m) {
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
   A(g->ck, L * B * d * g->kvp);
   A(g->cvt, L * B * d * g->kvp);
-  A(g->sk, L * R * NT * d);
-  A(g->sv, L * R * NT * d);
+  A(g->sk, L * (size_t)g->self_cap * d);
+  A(g->sv, L * (size_t)g->self_cap * d);
   A(g->x, R * d); A(g->qkv, R * 3 * d); A(g->att, R * d); A(g->qc, R * d);
   A(g->ffn, R * 4 * d);
   A(g->logits, R * c.n_vocab);
@@ -154,6 +169,15 @@ int gen_workspace_ensure(Model* m) {
   const char* ng = getenv("FWAMD_NO_GRAPH");   // rocprofv3 7.2 crashes on replayed graphs: profile eagerly
   g->graphs_enabled = !(ng && ng[0] == '1');
   return FW_OK;
+}
+
+// A workspace is installed whole or not at all: after a failed build (argument check, out of HBM) the next call
+// starts from scratch instead of launching kernels on a half-allocated one.
+int gen_workspace_ensure(Model* m) {
+  if (m->gen) return FW_OK;
+  const int rc = gen_workspace_build(m);
+  if (rc) gen_workspace_free(m);
+  return rc;
 }
 
 void gen_workspace_free(Model* m) {
@@ -267,8 +291,9 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   const int frag = i8 ? 0 : 1;
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
-    half_t* kc = g->sk + (size_t)l * g->R * NT * d;
-    half_t* vc = g->sv + (size_t)l * g->R * NT * d;
+    // the run's own cache geometry: [layer][cache_rows slots][H][ctx][64]
+    half_t* kc = g->sk + (size_t)l * gp.cache_rows * gp.ctx * d;
+    half_t* vc = g->sv + (size_t)l * gp.cache_rows * gp.ctx * d;
     const half_t* ck = g->ck + (size_t)l * g->B * d * g->kvp;
     const half_t* cvt = g->cvt + (size_t)l * g->B * d * g->kvp;
     {
@@ -278,7 +303,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     }
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0, st);
-      fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, H, g->kvidx2, gp.K, s.kmul, frag ? g->att_frag : g->att, rows,
+      fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, gp.ctx, H, g->kvidx2, gp.K, s.kmul, frag ? g->att_frag : g->att, rows,
                             g->d_step, s.pos_fixed, s.P, gp.R, frag);
     }
     {
@@ -347,6 +372,11 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
 // generated-token budget: the reference treats max_length as prompt + new tokens
 // (transcribe.py:193-207). [CT2-ext] single place that decides; mirrors oracle.whisper.max_new_tokens.
 static int max_new_tokens(int max_length, int P) { return std::max(0, max_length - P); }
+// positions a run can reach (prompt + budget), rounded up to 8: the per-slot extent of its self-attention cache
+static int run_ctx(const fw_config& c, int max_length, int P) {
+  const int reach = P + max_new_tokens(std::min(max_length, c.n_text_ctx), P);
+  return std::min(c.n_text_ctx, (std::max(reach, 1) + 7) / 8 * 8);
+}
 
 static int check_launch(const char* what) {
   hipError_t he = hipGetLastError();
@@ -390,6 +420,15 @@ static bool mergeable(const GenRequest& a, const GenRequest& b) {
   return a.with_ts == b.with_ts && a.sot_pos == b.sot_pos;
 }
 
+// chunks of a run led by `r` that fit the self-attention cache (before the workspace exists: its planned size)
+static int64_t self_chunk_capacity(Model* dm, const GenRequest& r) {
+  if (r.sampling) return r.B;
+  const int B = std::max(dm->decode_batch, dm->max_batch);
+  const int nts = self_positions(dm, B, dm->decode_self_ctx > 0 ? dm->decode_self_ctx : dm->cfg.n_text_ctx);
+  const int64_t cap = (int64_t)B * dm->max_beam * nts;
+  return std::max<int64_t>(r.B, cap / ((int64_t)r.o->beam_size * run_ctx(dm->cfg, r.o->max_length, r.P)));
+}
+
 // Decode run over the concatenated chunks of `reqs` (all mergeable with reqs[0]).  Caller holds m->dec_mu.
 static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   int rc = gen_workspace_ensure(m);
@@ -408,6 +447,8 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   FW_CHECK_ARG(Bx * K <= g->R && Bx <= g->R && B <= g->B, "decode run of %d chunks x %d rows exceeds the workspace", B,
                kv_div * K);
   const int budget = max_new_tokens(std::min(o->max_length, c.n_text_ctx), P);
+  const int ctx = run_ctx(c, o->max_length, P);
+  FW_CHECK_ARG((int64_t)Bx * K * ctx <= g->self_cap, "decode run of %d rows x %d positions exceeds the self-attention cache", Bx * K, ctx);
   FW_HIP(hipSetDevice(m->device));
   hipStream_t st = m->dec_stream;
   {
@@ -420,6 +461,7 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
   gp.B = Bx; gp.K = K; gp.R = Bx * K; gp.P = P; gp.budget = budget; gp.kv_div = kv_div;
+  gp.ctx = ctx; gp.cache_rows = Bx * K;
   gp.sample = sampling ? 1 : 0;
   gp.inv_temp = sampling ? 1.0f / o->sampling_temperature : 1.0f;
   gp.seed_lo = (unsigned)(o->seed & 0xffffffffu);
@@ -555,8 +597,8 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   std::vector<int> n_fin(Bx), fin_len((size_t)Bx * FIN_CAP);
   std::vector<float> fin_score((size_t)Bx * FIN_CAP), nsp(Bx);
   std::vector<int> fin_tok((size_t)Bx * FIN_CAP * NT);
-  // (on the decode stream, not the legacy default stream: a default-stream copy would wait for every BLOCKING
-  //  stream of the device, and the CU-masked encoder streams of fw_model_set_encoder_cus are blocking streams)
+  // (on the decode stream, not the legacy default stream: a default-stream copy would wait for every blocking
+  //  stream of the device)
   FW_HIP(hipMemcpyAsync(n_fin.data(), g->n_fin, Bx * sizeof(int), hipMemcpyDeviceToHost, st));
   FW_HIP(hipMemcpyAsync(fin_len.data(), g->fin_len, fin_len.size() * sizeof(int), hipMemcpyDeviceToHost, st));
   FW_HIP(hipMemcpyAsync(fin_score.data(), g->fin_score, fin_score.size() * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -668,29 +710,34 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
       grp.cv.wait(lk);
       continue;
     }
-    // lead the next run: wait a moment for the requests of workers that are still encoding (they arrive within
-    // one encoder pass) unless half of the workspace is already claimed, then take every queued request that can
-    // share a run with the oldest one
+    // lead the next run: wait for the requests of workers that are still encoding (each arrives within one
+    // encoder pass) unless half of the workspace is already claimed, then take every queued request that can share
+    // a run with the oldest one.  The wait trades this caller's latency for rows per run; it is bounded by the
+    // merge-wait knob (fw_model_set_merge_wait: default one measured encoder pass after the last arrival, at most
+    // 120 ms; 0 = never) and skipped when no member encode is in flight.
     grp.leader_active = true;
     const int cap = std::max(dm->decode_batch, dm->max_batch);
-    if (cap > dm->max_batch && !grp.queue.front()->sampling) {
+    int wait_ms = grp.merge_wait_ms.load();
+    if (wait_ms < 0) wait_ms = std::min(120, std::max(5, (grp.enc_pass_us.load() * 5 / 4 + 999) / 1000));
+    if (cap > dm->max_batch && wait_ms > 0 && !grp.queue.front()->sampling) {
       // (waiting for a quarter, a half or the whole workspace measured the same throughput within 1 %:
       //  profiles/r02_mid_*; one half keeps two runs alternating, so encoders and result handling overlap a run)
       for (;;) {
         int queued = 0;
         for (const GenRequest* r : grp.queue) queued += r->B;
         if (queued * 2 >= cap || grp.encoding.load() <= 0) break;
-        // requests keep arriving one encoder pass apart: give up 120 ms after the last arrival
-        if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(120)) break;
+        if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(wait_ms)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
       }
     }
     std::vector<GenRequest*> batch;
     GenRequest* first = grp.queue.front();
     int chunks = 0;
+    // chunks the self-attention cache holds at this call's context (mergeable calls share max_length and P)
+    const int run_cap = std::min<int64_t>(cap, self_chunk_capacity(dm, *first));
     for (auto it = grp.queue.begin(); it != grp.queue.end();) {
       GenRequest* r = *it;
-      if (r == first || (mergeable(*first, *r) && chunks + r->B <= cap)) {
+      if (r == first || (mergeable(*first, *r) && chunks + r->B <= run_cap)) {
         batch.push_back(r);
         chunks += r->B;
         it = grp.queue.erase(it);
@@ -828,6 +875,7 @@ int32_t fw_detect_language(fw_model* fm, const fw_tensor* enc_t, int32_t B, int3
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
   gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = 1; gp.V = c.n_vocab; gp.n_text_ctx = g->NT; gp.kv_div = 1;
+  gp.ctx = 8; gp.cache_rows = B * m->max_beam;
   std::vector<int> tok(B, c.tok_sot);
   FW_HIP(hipMemsetAsync(g->kvidx2, 0, 2 * (size_t)g->R * g->NT, st));
   FW_HIP(hipMemsetAsync(g->d_step, 0, sizeof(int), st));
@@ -1064,6 +1112,7 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
   gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = max_tok; gp.V = c.n_vocab; gp.n_text_ctx = g->NT; gp.kv_div = 1;
+  gp.ctx = std::min(g->NT, (max_tok + 7) / 8 * 8); gp.cache_rows = B * m->max_beam;   // <= EB * K * NT <= self_cap
   for (int pos = 0; pos < max_tok; ++pos) {
     StepCfg s;
     s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = pos; s.P = max_tok; s.tok = g->prompt_dev + (size_t)pos * B;

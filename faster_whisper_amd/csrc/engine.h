@@ -108,6 +108,8 @@ struct DecodeGroup {
   std::atomic<int> encoding{0};   // member encodes in flight: requests that are about to arrive
   std::chrono::steady_clock::time_point last_arrival{};   // when the newest request was queued
   std::mutex enc_mu;              // one encoder pass at a time per device
+  std::atomic<int> enc_pass_us{0};   // running mean of the time a member holds enc_mu (one encoder pass)
+  std::atomic<int> merge_wait_ms{-1};   // fw_model_set_merge_wait: -1 = one encoder pass (<= 120 ms), 0 = never wait
   // statistics (fw_model_decode_stats): decode runs, fw_generate calls served, chunks decoded, largest run
   std::atomic<int64_t> n_runs{0}, n_requests{0}, n_chunks{0};
   std::atomic<int> max_run_chunks{0};
@@ -165,7 +167,11 @@ struct Model {
   GenWorkspace* gen = nullptr;
   Model* decoder = nullptr;
   int decode_batch = 0;
-  int encoder_cus = 0;       // CUs the encoder stream is confined to (0 = all): fw_model_set_encoder_cus
+  int decode_self_ctx = 0;   // self-attention cache positions per row at full row capacity (0 = the text context)
+  int dependents = 0;        // live models that use this one's weight blob or decode workspace (g_models_mu)
+  bool free_deferred = false;   // fw_model_free was called while dependents > 0: freed with the last dependent
+  void* self = nullptr;         // the fw_model this Model lives in
+  Model* blob_owner = nullptr;  // the model whose blob this one borrows (fw_model_create_from_blob_dev on fw_model_blob)
   hipStream_t dec_stream = nullptr;
   std::mutex dec_mu;
   DecodeGroup grp;
@@ -174,7 +180,9 @@ struct Model {
   std::mutex pool_mu;
   std::vector<half_t*> enc_pool;
 
-  // profiling
+  // profiling.  The encoder thread of the model (under mu) and the leader of a decode run (under dec_mu, any worker
+  // thread) both record scopes on the same model, so the event lists have a mutex of their own.
+  std::mutex prof_mu;
   bool prof_on = false;
   ProfAcc prof[PF_COUNT];
   struct PendingEv { hipEvent_t a, b; int fam; };
@@ -212,7 +220,7 @@ int run_encoder(Model* m, int B, half_t* out);
 uint64_t next_tensor_id();
 int gen_workspace_ensure(Model* dm);          // creates dm's decode workspace on first use (caller holds dm->dec_mu)
 void gen_workspace_free(Model* m);
-int64_t gen_workspace_bytes(const Model* m, int decode_batch);
+int64_t gen_workspace_bytes(const Model* m, int decode_batch, int self_ctx);   // self_ctx 0 = the text context
 inline Model* decoder_of(Model* m) { return m->decoder ? m->decoder : m; }
 
 }  // namespace fw

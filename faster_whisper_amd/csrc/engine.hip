@@ -57,28 +57,42 @@ static hipEvent_t ev_get(Model* m) {
 ProfScope::ProfScope(Model* m_, int fam_, double flops, double bytes, hipStream_t st_)
     : m(m_), fam(fam_), st(st_ ? st_ : m_->stream) {
   if (!m->prof_on) return;
-  a = ev_get(m);
-  b = ev_get(m);
-  m->prof[fam].flops += flops;
-  m->prof[fam].bytes += bytes;
-  m->prof[fam].launches += 1;
+  {
+    std::lock_guard<std::mutex> lk(m->prof_mu);
+    a = ev_get(m);
+    b = ev_get(m);
+    m->prof[fam].flops += flops;
+    m->prof[fam].bytes += bytes;
+    m->prof[fam].launches += 1;
+  }
   (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
   if (!a) return;
   (void)hipEventRecord(b, st);
+  std::lock_guard<std::mutex> lk(m->prof_mu);
   m->pending.push_back({a, b, fam});
 }
 void prof_collect(Model* m) {
-  for (auto& p : m->pending) {
+  // the events are waited for outside the lock (a scope of the other stream may be recorded meanwhile)
+  std::vector<Model::PendingEv> todo;
+  {
+    std::lock_guard<std::mutex> lk(m->prof_mu);
+    todo.swap(m->pending);
+  }
+  std::vector<std::pair<int, float>> got;
+  for (auto& p : todo) {
     (void)hipEventSynchronize(p.b);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, p.a, p.b);
-    m->prof[p.fam].ms += ms;
+    got.push_back({p.fam, ms});
+  }
+  std::lock_guard<std::mutex> lk(m->prof_mu);
+  for (auto& g : got) m->prof[g.first].ms += g.second;
+  for (auto& p : todo) {
     m->ev_pool.push_back(p.a);
     m->ev_pool.push_back(p.b);
   }
-  m->pending.clear();
 }
 
 // ---------------------------------------------------------------- fp16 helpers (host)
@@ -637,6 +651,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
                            int max_beam, fw_model** out) {
   FW_CHECK_ARG(max_batch >= 1 && max_batch <= 256, "max_batch must be in [1,256], got %d", max_batch);
   FW_CHECK_ARG(max_beam >= 1 && max_beam <= 16, "max_beam must be in [1,16], got %d", max_beam);
+  FW_CHECK_ARG(max_batch * max_beam <= 2048, "max_batch * max_beam must be <= 2048 decoder rows, got %d", max_batch * max_beam);
   FW_CHECK_ARG(blob_bytes >= (int64_t)sizeof(BlobHeader), "weight blob too small");
   BlobHeader h;
   FW_HIP(hipMemcpy(&h, blob_dev, sizeof(h), hipMemcpyDeviceToHost));
@@ -689,9 +704,15 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
     return fail(FW_ENODEV);
   }
   {
+    // a model on a borrowed blob (fw_model_create_from_blob_dev on fw_model_blob's pointer) keeps the owner alive:
+    // fw_model_free(owner) is deferred until its last dependent is gone
     std::lock_guard<std::mutex> lk(g_models_mu_ref());
+    if (!owned)
+      for (Model* o : g_live_models_ref())
+        if (o->blob == m->blob && o->blob_owned) { m->blob_owner = o; o->dependents += 1; break; }
     g_live_models_ref().push_back(m);
   }
+  m->self = fm;
   *out = fm;
   return FW_OK;
 }
@@ -1020,9 +1041,16 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
 void fw_model_free(fw_model* fm) {
   if (!fm) return;
   Model* m = &fm->impl;
+  Model* release[2] = {nullptr, nullptr};
   {
     std::lock_guard<std::mutex> lk(g_models_mu);
+    if (m->dependents > 0) {   // workers still use this model's weights / decode workspace: freed with the last one
+      m->free_deferred = true;
+      return;
+    }
     g_live_models.erase(std::remove(g_live_models.begin(), g_live_models.end(), m), g_live_models.end());
+    release[0] = m->blob_owner;
+    release[1] = m->decoder;
   }
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
@@ -1041,6 +1069,16 @@ void fw_model_free(fw_model* fm) {
   for (auto e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete fm;
+  for (Model* t : release) {
+    if (!t) continue;
+    bool free_now = false;
+    {
+      std::lock_guard<std::mutex> lk(g_models_mu);
+      t->dependents -= 1;
+      free_now = t->free_deferred && t->dependents == 0;
+    }
+    if (free_now) fw_model_free(static_cast<fw_model*>(t->self));
+  }
 }
 
 int32_t fw_model_blob(const fw_model* fm, void** blob_dev, int64_t* blob_bytes) {
@@ -1069,56 +1107,43 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   FW_CHECK_ARG(decode_batch >= 1, "decode_batch must be positive");
   std::lock_guard<std::mutex> lk(m->dec_mu);
   FW_HIP(hipSetDevice(m->device));
-  // whole encoder batches, at least one, at most what fits in 70 % of the free HBM (and 2048 rows)
+  // Whole encoder batches, at least one, at most 2048 rows, in 70 % of the free HBM.  The cross-attention cache is
+  // fixed per chunk; the self-attention cache is rows x positions and a RUN lays it out for its own max_length
+  // (decoder.hip), so when the requested chunks do not fit with the whole text context per row, the positions per
+  // row are lowered first (down to 128: a run that asks for more then simply holds fewer rows) and only then the
+  // chunk count.
   int want = std::max(decode_batch, m->max_batch) / m->max_batch * m->max_batch;
+  while (want > m->max_batch && (int64_t)want * m->max_beam > 2048) want -= m->max_batch;
   size_t free_b = 0, total_b = 0;
   FW_HIP(hipMemGetInfo(&free_b, &total_b));
-  if (m->gen) free_b += (size_t)gen_workspace_bytes(m, m->decode_batch);
-  while (want > m->max_batch &&
-         (gen_workspace_bytes(m, want) > (int64_t)(0.7 * (double)free_b) || (int64_t)want * m->max_beam > 2048))
+  if (m->gen) free_b += (size_t)gen_workspace_bytes(m, m->decode_batch, m->decode_self_ctx);
+  const int64_t budget = (int64_t)(0.7 * (double)free_b);
+  const int NT = m->cfg.n_text_ctx;
+  const int ctx_steps[] = {NT, 320, 224, 160, 128};
+  int self_ctx = NT;
+  for (;;) {
+    bool fits = false;
+    for (int cs : ctx_steps) {
+      if (cs > NT) continue;
+      if (gen_workspace_bytes(m, want, cs) <= budget) { self_ctx = cs; fits = true; break; }
+    }
+    if (fits || want <= m->max_batch) break;
     want -= m->max_batch;
-  if (m->gen && want == m->decode_batch) return FW_OK;
+  }
+  if (m->gen && want == m->decode_batch && self_ctx == m->decode_self_ctx) return FW_OK;
   if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
   gen_workspace_free(m);
   m->decode_batch = want;
+  m->decode_self_ctx = self_ctx;
   return gen_workspace_ensure(m);
 }
 
-// CU mask of n = 32k CUs, 4k in every XCD.  Whether bit i of a HIP CU mask is CU (i % 32) of XCD (i / 32) or CU
-// (i / 8) of XCD (i % 8) is not documented; (i%8 + i/8) % 8 < k selects k of every 8 consecutive CUs of an XCD under
-// either reading.  (A finer, 8-CU granularity was tried with a second balanced split of the partial class; the
-// encoder GEMM — whose tile -> XCD mapping assumes equal XCDs — ran 45 % slower at 112 CUs than at 96.)
-static void balanced_cu_mask(int n_cus, uint32_t mask[8]) {
-  const int k = n_cus / 32;
-  for (int w = 0; w < 8; ++w) mask[w] = 0;
-  for (int i = 0; i < 256; ++i)
-    if (((i % 8) + (i / 8)) % 8 < k) mask[i >> 5] |= 1u << (i & 31);
-}
-
-int32_t fw_model_set_encoder_cus(fw_model* fm, int32_t n_cus) {
+int32_t fw_model_set_merge_wait(fw_model* fm, int32_t wait_ms) {
   FW_CHECK_ARG(fm, "null model");
-  Model* m = &fm->impl;
-  FW_CHECK_ARG(n_cus == 0 || (n_cus >= 32 && n_cus <= 256 && n_cus % 32 == 0),
-               "encoder CUs: 0 (all) or a multiple of 32 in [32, 256]");
-  FW_HIP(hipSetDevice(m->device));
-  hipStream_t fresh = nullptr;
-  if (n_cus == 0 || n_cus == 256) {
-    FW_HIP(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
-  } else {
-    uint32_t mask[8];
-    balanced_cu_mask(n_cus, mask);
-    FW_HIP(hipExtStreamCreateWithCUMask(&fresh, 8, mask));
-  }
-  if (m->stream) {
-    (void)hipStreamSynchronize(m->stream);
-    (void)hipStreamDestroy(m->stream);
-  }
-  m->stream = fresh;
-  m->encoder_cus = (n_cus == 256) ? 0 : n_cus;
+  FW_CHECK_ARG(wait_ms >= -1 && wait_ms <= 10000, "merge wait: -1 (one encoder pass), 0 (never) or milliseconds <= 10000");
+  decoder_of(&fm->impl)->grp.merge_wait_ms.store(wait_ms);
   return FW_OK;
 }
-
-int32_t fw_model_encoder_cus(const fw_model* fm) { return fm ? fm->impl.encoder_cus : 0; }
 
 int32_t fw_model_decode_batch(const fw_model* fm) {
   if (!fm) return 0;
@@ -1144,10 +1169,15 @@ int32_t fw_model_join_decoder(fw_model* fm, fw_model* decoder) {
   FW_CHECK_ARG(!d->decoder, "the decoder model has itself joined another decoder");
   FW_CHECK_ARG(m->device == d->device && m->blob == d->blob && m->max_batch == d->max_batch && m->max_beam == d->max_beam,
                "models that share a decoder must share device, weight blob, max_batch and max_beam");
+  FW_CHECK_ARG(!m->decoder, "this model has already joined a decoder");
   std::lock_guard<std::mutex> lk(m->dec_mu);
   FW_HIP(hipSetDevice(m->device));
   if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
   gen_workspace_free(m);
+  {
+    std::lock_guard<std::mutex> lk2(g_models_mu);   // the primary outlives its workers (fw_model_free defers)
+    d->dependents += 1;
+  }
   m->decoder = d;
   return FW_OK;
 }
@@ -1215,14 +1245,19 @@ namespace {
 // for it instead of starting with a nearly empty workspace)
 struct EncodingMark {
   fw::DecodeGroup& g;
+  std::chrono::steady_clock::time_point t0;
   explicit EncodingMark(fw::Model* m) : g(fw::decoder_of(m)->grp) {
     g.encoding.fetch_add(1);
     // One encoder pass at a time per device: a pass fills the chip by itself, several at once only time-slice
     // (measured +1.5 % throughput with the lock, and per-kernel event timings stay meaningful).  The decode run of
     // the group keeps going on its own stream next to it.
     g.enc_mu.lock();
+    t0 = std::chrono::steady_clock::now();
   }
   ~EncodingMark() {
+    const int us = (int)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    const int old = g.enc_pass_us.load();
+    g.enc_pass_us.store(old ? (3 * old + us) / 4 : us);
     g.enc_mu.unlock();
     g.encoding.fetch_sub(1);
     g.cv.notify_all();
@@ -1378,6 +1413,7 @@ void fw_prof_enable(fw_model* fm, int32_t on) { if (fm) fm->impl.prof_on = on !=
 void fw_prof_reset(fw_model* fm) {
   if (!fm) return;
   prof_collect(&fm->impl);
+  std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
   for (auto& p : fm->impl.prof) p = ProfAcc();
 }
 int32_t fw_prof_count(void) { return PF_COUNT; }
@@ -1385,6 +1421,7 @@ const char* fw_prof_name(int32_t i) { return (i >= 0 && i < PF_COUNT) ? kProfNam
 int32_t fw_prof_get(fw_model* fm, int32_t i, double* ms, int64_t* launches, double* flops, double* bytes) {
   FW_CHECK_ARG(fm && i >= 0 && i < PF_COUNT, "bad profile index");
   prof_collect(&fm->impl);
+  std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
   const ProfAcc& p = fm->impl.prof[i];
   if (ms) *ms = p.ms;
   if (launches) *launches = p.launches;

@@ -142,8 +142,8 @@ int32_t fw_model_info(const fw_model* m, fw_config* cfg_out, int32_t* compute_ty
                       int32_t* device_index, int32_t* max_batch, int32_t* max_beam);
 /* Device address / size of a model's weight blob: lets N worker replicas on one GPU share one copy
  * of the weights (CTranslate2's inter_threads / faster-whisper's num_workers, transcribe.py:654-657):
- * create the extra replicas with fw_model_create_from_blob_dev on this pointer. The owning model
- * must outlive them. */
+ * create the extra replicas with fw_model_create_from_blob_dev on this pointer.  fw_model_free of the owning
+ * model (and of the primary of a decode group) is deferred until its last dependent has been freed. */
 int32_t fw_model_blob(const fw_model* m, void** blob_dev, int64_t* blob_bytes);
 /* Same model from a weight blob that is ALREADY in HBM on `device_index`
  * (the RCCL-broadcast path: rank 0 packs, ranks receive into device memory).
@@ -156,7 +156,9 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
  * GPU with 288 GB of HBM.  A decode step streams every decoder weight once whatever the number of rows, so the
  * worker replicas of a device share ONE decode workspace instead of decoding side by side:
  *   fw_model_set_decode_batch(primary, n_workers * max_batch)  sizes the primary's decode workspace for that many
- *       chunks (rounded down to whole encoder batches and to what fits in HBM; fw_model_decode_batch reads it back);
+ *       chunks (rounded down to whole encoder batches, 2048 rows and what fits in HBM; fw_model_decode_batch reads it
+ *       back).  The self-attention cache is rows x positions and every run lays it out for its own max_length, so a
+ *       run of calls with a short max_length holds more chunks than one that asks for the whole text context;
  *   fw_model_join_decoder(worker, primary)  frees the worker's own decode workspace and routes its fw_generate /
  *       fw_detect_language / fw_align calls to the primary's.
  * fw_generate calls with identical options that arrive from different host threads while a decode run is in
@@ -165,15 +167,11 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
 int32_t fw_model_set_decode_batch(fw_model* m, int32_t decode_batch);
 int32_t fw_model_decode_batch(const fw_model* m);
 int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
-/* Compute-unit partition between the encoder and the decode group of a device.  The encoder GEMM is MFMA-bound and
- * holds a CU's whole register file and LDS; the decode step is HBM- and latency-bound and cannot co-reside with it.
- * Left alone the two time-slice the chip (wall = encoder + decode).  Confining the ENCODER stream of every replica
- * to n_cus CUs (a multiple of 32 in [32, 256], the same number in every XCD; 0 = no confinement) leaves the other
- * CUs to the decode run at all times, so the two overlap.  Recreates the model's encoder stream: call it after
- * fw_model_create and before the first encode, from one thread.  (No counterpart in the reference: CTranslate2
- * replicas share a GPU through the driver's time slicing, transcribe.py:645-657.) */
-int32_t fw_model_set_encoder_cus(fw_model* m, int32_t n_cus);
-int32_t fw_model_encoder_cus(const fw_model* m);
+/* How long the leader of a decode run waits for the requests of workers that are still encoding (latency of the
+ * waiting call against rows per run): -1 = one measured encoder pass after the last arrival, at most 120 ms
+ * (default); 0 = never wait (every call starts its run at once: lowest latency); n > 0 = n milliseconds.  It never
+ * waits when no member encode is in flight. */
+int32_t fw_model_set_merge_wait(fw_model* m, int32_t wait_ms);
 /* counters of the decode group `m` belongs to: decode runs, fw_generate calls served, chunks decoded, chunks of
  * the largest run (any pointer may be NULL) */
 int32_t fw_model_decode_stats(const fw_model* m, int64_t* runs, int64_t* requests, int64_t* chunks,
@@ -269,45 +267,6 @@ int32_t fw_dev_alloc(fw_model* m, int64_t bytes, void** out_dev);
 int32_t fw_dev_free(fw_model* m, void* dev);
 int32_t fw_dev_upload(fw_model* m, void* dst_dev, const void* src_host, int64_t bytes);
 
-/* ---- kernel unit-test hooks (tests/ only; thin wrappers over single kernels
- * operating on host buffers, so each kernel is parity-tested in isolation) -- */
-int32_t fw_test_gemm(fw_model* m, const float* A, const float* W, const float* bias, const float* residual,
-                     int32_t M, int32_t N, int32_t K, int32_t act_gelu, int32_t use_int8, float* out);
-/* one decoder linear exactly as a decode step runs it (fragment-major operands, LayerNorm folded when ln_g/ln_b are
- * given, GELU when act = 1, residual added last): x [R][K], W [N][K], bias [N] | NULL, res [R][N] | NULL ->
- * out [R][N] (row-major result) and out_from_frag [R][N] (the fragment-major copy the next linear reads, un-permuted
- * on the host).  use_int8 = 0: what a decode step launches for this row count; 1: the int8_float16 form (needs an
- * int8_float16 model; ln must be NULL); 2 / 3 / 4: the GEMM-shaped kernel of large merged runs (dec_gemm_tile_kernel,
- * 2-, 3-, 4-stage forms) whatever the row count; 5: the skinny kernel whatever the row count.  0, 2-5 return the same bits. */
-int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const float* bias, const float* ln_g,
-                           const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
-                           int32_t use_int8, float* out, float* out_from_frag);
-/* the vocabulary projection of a decode step: x [R][d] raw residual rows -> float32 logits [R][n_vocab] (final
- * LayerNorm folded in fp16 mode, applied by the row quantiser in int8_float16 mode), with the model's own weights */
-int32_t fw_test_dec_logits(fw_model* m, const float* x, int32_t R, float* out);
-/* one launch of the logits-rules kernel (suppress lists, repetition penalty, no-repeat n-gram, timestamp rules,
- * log-softmax, top-2K candidates of cum + logp, or the Gumbel arg-max when opts selects sampling) on caller-provided
- * logits [R][n_vocab] and row state: hist [R][n] = the n tokens generated so far on each row, cum [R].  Outputs
- * cand_val / cand_tok [R][2 * beam_size] ([R][1] when sampling).  Replaces nothing in the reference: it exposes the
- * device form of CTranslate2's logits processors to tests/test_gpu_logits_rules.py. */
-int32_t fw_test_logits_rules(fw_model* m, const float* logits, int32_t R, const int32_t* hist, int32_t n,
-                             const float* cum, const fw_gen_opts* opts, int32_t with_timestamps, float* cand_val,
-                             int32_t* cand_tok);
-/* measurement hook (profiles/gemm_bench.py): average milliseconds of one launch of the "many rows" GEMM
- * C[batch][M][N] = A[batch][M][K] W[N][K]^T on device-resident pseudo-random operands (fp16, or int8 on an
- * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
-int32_t fw_bench_gemm(fw_model* m, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
-                      int32_t trans, int32_t iters, float* ms_out);
-/* micro-benchmark of the decoder linear kernel (dec_gemm_frag_kernel) for a tile-shape `variant` (dec_kernels.hip:
- * launch_dec_gemm_frag_variant; 0 / 1 = the product's) over a rotating weight set larger than the caches:
- * mean microseconds per launch of a [R] x [N][K] linear (lnf = LayerNorm-folded form). */
-int32_t fw_bench_dec_linear(fw_model* m, int32_t R, int32_t N, int32_t K, int32_t lnf, int32_t variant, int32_t iters,
-                            float* us_out);
-int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const float* b,
-                          int32_t rows, int32_t d, float* out);
-int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,
-                          int32_t B, int32_t H, int32_t T, float* out);
-
 /* ---- Silero VAD network (host) ----------------------------------------------
  * Replaces the reference's SileroVADModel (faster_whisper/vad.py:295-351: onnxruntime on the CPU, one thread,
  * asset silero_vad_v6.onnx).  Host C++: needs no GPU.  The weights are the initializers of that ONNX file, passed
@@ -334,9 +293,9 @@ int32_t fw_vad_forward(fw_vad* v, const float* windows, int64_t n, int32_t n_thr
                        float* probs);
 void fw_vad_free(fw_vad* v);
 /* Same computation on HIP device `device_index` (csrc/vad.hip: one workgroup per window for the front end, one
- * persistent workgroup for the LSTM recurrence); host pointers in and out.  Written after round 1's GPU budget
- * was spent: compiles, not yet validated on hardware — fw_vad_forward (host) is what the Python front uses by
- * default. */
+ * persistent workgroup for the LSTM recurrence); host pointers in and out.  Checked on hardware against the host
+ * path and against the numpy restatement of the ONNX graph (tests/test_gpu_vad.py); the Python front uses the host
+ * path by default (the reference runs the VAD on the CPU, vad.py:295-351). */
 int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows, int64_t n, float* h, float* c,
                            float* probs);
 

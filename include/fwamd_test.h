@@ -1,0 +1,55 @@
+/*
+ * fwamd_test.h — test and measurement hooks of libfwamd.so.  NOT part of the drop-in boundary (include/fwamd.h):
+ * thin wrappers over single kernels on host buffers, so that tests/ can parity-test each kernel in isolation and
+ * profiles/ can time one kernel outside the pipeline.  Nothing in faster_whisper_amd/ (the product) calls them.
+ */
+#ifndef FWAMD_TEST_H
+#define FWAMD_TEST_H
+
+#include "fwamd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int32_t fw_test_gemm(fw_model* m, const float* A, const float* W, const float* bias, const float* residual,
+                     int32_t M, int32_t N, int32_t K, int32_t act_gelu, int32_t use_int8, float* out);
+/* one decoder linear exactly as a decode step runs it (fragment-major operands, LayerNorm folded when ln_g/ln_b are
+ * given, GELU when act = 1, residual added last): x [R][K], W [N][K], bias [N] | NULL, res [R][N] | NULL ->
+ * out [R][N] (row-major result) and out_from_frag [R][N] (the fragment-major copy the next linear reads, un-permuted
+ * on the host).  use_int8 = 0: what a decode step launches for this row count; 1: the int8_float16 form (needs an
+ * int8_float16 model; ln must be NULL); 2 / 3 / 4: the GEMM-shaped kernel of large merged runs (dec_gemm_tile_kernel,
+ * 2-, 3-, 4-stage forms) whatever the row count; 5: the skinny kernel whatever the row count.  0, 2-5 return the same bits. */
+int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const float* bias, const float* ln_g,
+                           const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
+                           int32_t use_int8, float* out, float* out_from_frag);
+/* the vocabulary projection of a decode step: x [R][d] raw residual rows -> float32 logits [R][n_vocab] (final
+ * LayerNorm folded in fp16 mode, applied by the row quantiser in int8_float16 mode), with the model's own weights */
+int32_t fw_test_dec_logits(fw_model* m, const float* x, int32_t R, float* out);
+/* one launch of the logits-rules kernel (suppress lists, repetition penalty, no-repeat n-gram, timestamp rules,
+ * log-softmax, top-2K candidates of cum + logp, or the Gumbel arg-max when opts selects sampling) on caller-provided
+ * logits [R][n_vocab] and row state: hist [R][n] = the n tokens generated so far on each row, cum [R].  Outputs
+ * cand_val / cand_tok [R][2 * beam_size] ([R][1] when sampling).  Replaces nothing in the reference: it exposes the
+ * device form of CTranslate2's logits processors to tests/test_gpu_logits_rules.py. */
+int32_t fw_test_logits_rules(fw_model* m, const float* logits, int32_t R, const int32_t* hist, int32_t n,
+                             const float* cum, const fw_gen_opts* opts, int32_t with_timestamps, float* cand_val,
+                             int32_t* cand_tok);
+/* measurement hook (profiles/gemm_bench.py): average milliseconds of one launch of the "many rows" GEMM
+ * C[batch][M][N] = A[batch][M][K] W[N][K]^T on device-resident pseudo-random operands (fp16, or int8 on an
+ * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
+int32_t fw_bench_gemm(fw_model* m, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
+                      int32_t trans, int32_t iters, float* ms_out);
+/* micro-benchmark of the decoder linear kernel (dec_gemm_frag_kernel) for a tile-shape `variant` (dec_kernels.hip:
+ * launch_dec_gemm_frag_variant; 0 / 1 = the product's) over a rotating weight set larger than the caches:
+ * mean microseconds per launch of a [R] x [N][K] linear (lnf = LayerNorm-folded form). */
+int32_t fw_bench_dec_linear(fw_model* m, int32_t R, int32_t N, int32_t K, int32_t lnf, int32_t variant, int32_t iters,
+                            float* us_out);
+int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const float* b,
+                          int32_t rows, int32_t d, float* out);
+int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,
+                          int32_t B, int32_t H, int32_t T, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWAMD_TEST_H */

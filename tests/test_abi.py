@@ -1,4 +1,4 @@
-"""The C-ABI library loads, exports every symbol include/fwamd.h declares, and fails loudly
+"""The C-ABI library loads, exports every symbol include/*.h declare, and fails loudly
 (no CPU fallback) when no GPU is present.  No compute calls here."""
 import ctypes as C
 import os
@@ -10,7 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    src = open(os.path.join(ROOT, "include", "fwamd.h")).read()
+    src = ""
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):      # fwamd.h (the boundary) + fwamd_test.h (hooks)
+        if h.endswith(".h"):
+            src += open(os.path.join(ROOT, "include", h)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(fw_[a-z0-9_]+)\s*\(", src)))
 

@@ -134,28 +134,3 @@ def test_detect_language_and_align_through_a_worker():
     assert lang == lang1
     for a, b in zip(al, al1):
         assert a.alignments == b.alignments and a.text_token_probs == b.text_token_probs
-
-
-def test_encoder_cu_partition_changes_nothing_but_the_schedule():
-    """fw_model_set_encoder_cus confines the encoder streams to a subset of the CUs (so that the decode run of the
-    group always has the rest): same kernels, same launch geometry -> bit-identical encoder output and results"""
-    from faster_whisper_amd import Whisper, get_config, synthetic_weights
-    cfg = get_config("tiny.en")
-    w = synthetic_weights(cfg, seed=21)
-    common = dict(device="cuda", files={"config": cfg, "weights": w}, max_batch_size=3, max_beam_size=5,
-                  inter_threads=2)
-    free = Whisper("synthetic:tiny.en", encoder_cus=0, **common)
-    part = Whisper("synthetic:tiny.en", encoder_cus=96, **common)
-    lib = part._lib
-    assert [lib.fw_model_encoder_cus(r.handle) for r in part._replicas] == [96, 96]
-    assert [lib.fw_model_encoder_cus(r.handle) for r in free._replicas] == [0, 0]
-    assert lib.fw_model_set_encoder_cus(part._replicas[0].handle, 100) != 0      # not a multiple of 32: rejected
-    assert lib.fw_model_encoder_cus(part._replicas[0].handle) == 96
-    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
-    kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True)
-    for b in _batches(2, 3):
-        ea, eb = free.encode_pcm(b), part.encode_pcm(b)
-        assert np.array_equal(ea.to_numpy(), eb.to_numpy())
-        ga, gb = free.generate(ea, [prompt] * 3, **kw), part.generate(eb, [prompt] * 3, **kw)
-        for x, y in zip(ga, gb):
-            assert x.sequences_ids == y.sequences_ids and x.scores == y.scores
