@@ -1,26 +1,27 @@
 """Parity at BASELINE.json's benchmarked geometry: large-v3 shapes (d = 1280, ffn 5120, 32 + 32 layers, 128 mels,
-vocabulary 51 866), **16 chunks x beam 5 = 80 decoder rows** — the configuration bench.py times — on seeded
-synthetic weights, for float16, int8_float16 (C3) and distil-large-v3 (C5: 2 decoder layers).
+vocabulary 51 866), **16 chunks x beam 5 = 80 decoder rows** — the configuration bench.py times — and the MERGED
+decode runs bench.py actually executes (8 workers x 16 chunks = 640 rows in one run), on seeded synthetic weights,
+for float16, int8_float16 (C3) and distil-large-v3 (C5: 2 decoder layers).
 
 The engine always runs the whole batch of 16; the CPU oracle (fp16 storage emulated; int8 restated exactly) is run
 on a 2-chunk subset (first chunk, and one in the last row tile) because a large-v3 beam step costs about a second
 of CPU.  What is compared, per configuration:
   * encoder output of one chunk (relative max / rms error);
   * >= 8 teacher-forced greedy steps: log-prob of the engine's own ids under the oracle, per token;
-  * beam 5: score of the engine's hypothesis under the oracle, ids identical or tied (conftest.check_hypothesis),
-    no-speech probability;
-  * detect_language probabilities; align: token probabilities, word-boundary frames <= 2.
-Tolerances.  At this depth (32 + 32 layers of random weights) ANY two fp16 evaluations of the model differ at the
-1e-3 level, on the CPU alone (tests/numerics_ln_fold_noise.py -> tests/golden/numerics_ln_fold_noise.txt): fp16
-storage vs fp32 up to 8.5e-4 per token and 3.0e-3 on a language probability; the engine's evaluation order (decoder
-LayerNorms folded into the linears they feed, oracle `fold_ln`) vs the explicit order up to 1.4e-3 per token, 2.0e-3
-on a beam-5 score, 2.9e-3 on a language probability; two implementations of the SAME folded order still 6e-4 per
-token.  The north-star 1e-3 is therefore asserted where the model is shallow enough for it to be meaningful (micro,
-tiny.en: tests/test_gpu_model.py; distil-large-v3's 2-layer decoder here), every kernel is checked alone at these
-shapes at fp16 round-off (tests/test_gpu_kernels.py), and the large-v3 end-to-end figures are held to 2x the
-largest CPU-observed difference between valid fp16 orders: 3e-3 per token, 4e-3 beam score, 6e-3 / 5e-3 language /
-token probabilities.  A wiring error (wrong weight, wrong row, wrong layer) moves these by 1e-1, not 1e-3.
-(The int8_float16 tolerances and where they come from are next to the tolerance table in _run.)
+  * beam 5 over **48 steps** (self-attention over a long slot-table history; teacher-forced scoring keeps the oracle's
+    cost linear): score of the engine's hypothesis under the oracle, ids identical or tied
+    (conftest.check_hypothesis), no-speech probability;
+  * detect_language probabilities; align: token probabilities, word-boundary frames <= 2;
+  * merged decode runs (test_merged_run_*): every caller bit-identical to its solo call, the oracle on the first and
+    the last chunk of the merged run.
+
+Tolerances.  The north-star figure is NORTH_STAR = 1e-3 (BASELINE.json: "segment timestamps/logprobs within 1e-3 at
+beam_size=5") and it is what every quantity is asserted at, except the entries of EXCEPTIONS below, each with the
+value measured on the box and its cause.  Background for the fp16 exceptions: at this depth (32 + 32 layers) two valid
+fp16 evaluations of the model differ at the 1e-3 level on the CPU alone (tests/numerics_ln_fold_noise.py ->
+tests/golden/numerics_ln_fold_noise.txt: fp16 storage vs fp32 up to 3.0e-3 on a language probability; the engine's
+LayerNorm-folded order vs the explicit order up to 2.9e-3 on a probability), while every kernel alone is checked at
+these shapes at fp16 round-off (tests/test_gpu_kernels.py).  A wiring error moves these figures by 1e-1, not 1e-3.
 Reference call sites: transcribe.py:222-246 (generate + score), :1709-1746 (align), :1823-1828 (detect_language)."""
 import os
 
@@ -33,6 +34,28 @@ pytestmark = pytest.mark.gpu
 
 B = 16
 SUBSET = (0, 13)      # chunks the oracle is run on: rows 0-4 (first tile) and 65-69 (last tile of the 80)
+NORTH_STAR = 1e-3     # BASELINE.json north_star: log-probs / probabilities within 1e-3 of the reference path
+# (configuration, quantity) -> (asserted bound, largest value measured on the box, cause).  Everything not listed is
+# asserted at NORTH_STAR.  Quantities: tf = per-token teacher-forced log-prob, beam = beam score (relative to
+# max(1, |score|)), nsp = no-speech probability, lang / align = language / text-token probabilities.
+FP16_ORDER = "fp16 evaluation-order noise of a 32 + 32 layer model (CPU-measured between valid fp16 orders: 3e-3)"
+INT8_CODES = ("engine and oracle quantise activations that differ by fp16 rounding; flipped int8 codes accumulate over "
+              "2 x 32 quantised blocks (every int8 GEMM alone is bit-exact: tests/test_gpu_int8.py)")
+EXCEPTIONS = {
+    ("large-v3 float16", "lang"): (6e-3, 2.3e-3, FP16_ORDER),
+    ("large-v3 float16", "align"): (5e-3, 1.6e-3, FP16_ORDER),
+    ("distil-large-v3 float16", "lang"): (2e-3, 1.1e-3, FP16_ORDER + " (32-layer encoder feeding a softmax over 100 ids)"),
+    ("distil-large-v3 float16", "align"): (2e-3, 1.2e-3, FP16_ORDER),
+    ("large-v3 int8_float16", "tf"): (2e-2, 1.0e-2, INT8_CODES),
+    ("large-v3 int8_float16", "beam"): (4e-2, 3.2e-2, INT8_CODES),
+    ("large-v3 int8_float16", "nsp"): (1e-2, 2.0e-3, INT8_CODES),
+    ("large-v3 int8_float16", "lang"): (6e-2, 3.8e-2, INT8_CODES),
+    ("large-v3 int8_float16", "align"): (5e-2, 2.0e-2, INT8_CODES),
+}
+
+
+def tolerance(cfg_name, compute_type, what):
+    return EXCEPTIONS.get((f"{cfg_name} {compute_type}", what), (NORTH_STAR,))[0]
 
 
 @pytest.fixture(scope="module")
@@ -51,22 +74,16 @@ def _chunks():
     return out
 
 
-def _run(cfg, w, compute_type, tf_steps=8, beam_steps=6):
+def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
     from faster_whisper_amd import Whisper
     from faster_whisper_amd.backend import StorageView, language_token_strings
     from oracle.whisper import OracleWhisper
     i8 = compute_type == "int8_float16"
-    # Tolerances: module docstring (fp16).  distil-large-v3 (2 decoder layers) keeps the north-star figures.
-    # int8_float16: the engine and the oracle quantise activations that differ by fp16 rounding, a flipped int8 code
-    # is 1/127 of a row's range and 2 x 32 quantised blocks accumulate them: measured 1.3e-2 rms on the encoder
-    # output, 1e-2 per token on an 8-step log-prob, 2e-2 on a beam score, 3.8e-2 on a language probability — every
-    # single int8 GEMM is bit-exact against the integer reference (tests/test_gpu_int8.py).
-    if i8:
-        tol = dict(tf=2e-2, beam=4e-2, gap=6e-2, nsp=1e-2, lang=6e-2, align=5e-2, enc=(6e-2, 2e-2))
-    elif cfg.n_dec_layers <= 4:
-        tol = dict(tf=1e-3, beam=1e-3, gap=2e-2, nsp=1e-3, lang=2e-3, align=2e-3, enc=(3e-2, 5e-3))
-    else:
-        tol = dict(tf=3e-3, beam=4e-3, gap=2e-2, nsp=1e-3, lang=6e-3, align=5e-3, enc=(3e-2, 5e-3))
+    # Tolerances: NORTH_STAR everywhere except the listed EXCEPTIONS (module header).  Encoder output: relative max /
+    # rms error of one chunk (not a log-prob; the decoder quantities below are what the north star constrains).
+    tol = {k: tolerance(cfg.name, compute_type, k) for k in ("tf", "beam", "nsp", "lang", "align")}
+    tol["enc"] = (6e-2, 2e-2) if i8 else (3e-2, 5e-3)
+    tol["gap"] = 6e-2 if i8 else 2e-2      # beam hypotheses: how much worse than the oracle's best counts as a bug
     fails = []
 
     def expect(cond, msg):
@@ -163,7 +180,7 @@ def test_large_v3_float16(lv3):
 
 def test_large_v3_int8_float16(lv3):
     cfg, w = lv3
-    _run(cfg, w, "int8_float16", tf_steps=8, beam_steps=4)
+    _run(cfg, w, "int8_float16", tf_steps=8, beam_steps=48)
 
 
 def test_distil_large_v3_float16(lv3):
@@ -174,4 +191,100 @@ def test_distil_large_v3_float16(lv3):
     _, w = lv3
     cfg = get_config("distil-large-v3")
     wd = {k: w[k] for k in weight_shapes(cfg)}
-    _run(cfg, wd, "float16", tf_steps=12, beam_steps=10)
+    _run(cfg, wd, "float16", tf_steps=12, beam_steps=48)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Merged decode runs at the benchmarked geometry (what bench.py executes: the generate() calls of the workers of a
+# GPU share one decode run).  8 workers x 16 chunks x beam 5 = 640 rows in ONE run: the row-group paths of the
+# decoder linears (grid.y > 1, the GEMM-shaped kernel above its row threshold), the XCD-placed row groups of the
+# vocabulary projection and the per-run self-attention cache geometry, none of which a 16-chunk call reaches.
+# Reference behaviour: one generate() per batch, transcribe.py:222-246; CTranslate2 replicas decode side by side.
+# ---------------------------------------------------------------------------------------------------------------
+def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7, 15))):
+    import threading
+    import time
+    from faster_whisper_amd import Whisper
+    from oracle.whisper import OracleWhisper
+    i8 = compute_type == "int8_float16"
+    tag = f"[{cfg.name} {compute_type} merged]"
+    model = Whisper(f"synthetic:{cfg.name}", device="cuda", files={"config": cfg, "weights": w},
+                    compute_type=compute_type, max_batch_size=B, max_beam_size=5, inter_threads=workers)
+    assert model.decode_stats()["decode_batch"] >= workers * B
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    sup = [cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe]
+    kw = dict(beam_size=5, patience=1.0, length_penalty=1.0, max_length=len(prompt) + steps, suppress_tokens=sup,
+              return_scores=True, return_no_speech_prob=True)
+    pool = [bench_audio(480000, seed=300 + i) for i in range(24)]
+    batches = [[pool[(5 * i + 3 * j) % len(pool)][:480000 - 16000 * ((i + j) % 4)] for j in range(B)] for i in range(workers)]
+    batches[3] = batches[3][:11]                      # a smaller batch rides along
+    # ---- solo: one call at a time ----
+    encs = [model.encode_pcm(b) for b in batches]
+    solo = [model.generate(e, [prompt] * len(b), **kw) for e, b in zip(encs, batches)]
+    st0 = model.decode_stats()
+    # ---- merged: the callers queue up behind a run that is in progress and are taken together by the next one ----
+    out = [None] * workers
+    errs = []
+    go = threading.Event()
+    encoded = threading.Barrier(workers + 1)
+
+    def work(i):
+        try:
+            e = model.encode_pcm(batches[i])          # this thread's own worker replica
+            encoded.wait()
+            go.wait()
+            out[i] = model.generate(e, [prompt] * len(batches[i]), **kw)
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    def blocker():
+        try:
+            model.generate(encs[0], [prompt] * len(batches[0]), **dict(kw, max_length=len(prompt) + 4 * steps,
+                                                                      min_new_tokens=4 * steps))
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+    for t in ts:
+        t.start()
+    encoded.wait()                                    # every worker holds its encoder output
+    bt = threading.Thread(target=blocker)
+    bt.start()
+    t_end = time.time() + 60
+    while model.decode_stats()["runs"] == st0["runs"] and time.time() < t_end:
+        time.sleep(0.001)                             # the blocker's run has started
+    go.set()
+    for t in ts + [bt]:
+        t.join()
+    assert not errs, errs
+    st = model.decode_stats()
+    n_chunks = sum(len(b) for b in batches)
+    print(f"{tag} {workers} concurrent calls ({n_chunks} chunks) -> {st['runs'] - st0['runs'] - 1} decode run(s), "
+          f"largest run {st['max_run_chunks']} chunks = {5 * st['max_run_chunks']} rows")
+    assert st["max_run_chunks"] == n_chunks           # ONE run carried every caller
+    for i in range(workers):
+        for j, (a, b) in enumerate(zip(out[i], solo[i])):
+            assert a.sequences_ids == b.sequences_ids, (tag, i, j)
+            assert a.scores == b.scores and a.no_speech_prob == b.no_speech_prob, (tag, i, j, a.scores, b.scores)
+    # ---- the oracle on the first and the last chunk of the merged run ----
+    oracle = OracleWhisper(cfg, w, emulate_fp16=True, int8=i8)
+    okw = {k: v for k, v in kw.items() if k not in ("return_scores", "return_no_speech_prob")}
+    tb = tolerance(cfg.name, compute_type, "beam")
+    for (i, j) in oracle_chunks:
+        j = min(j, len(batches[i]) - 1)
+        e1 = model.encode_pcm([batches[i][j]]).to_numpy()
+        ref = oracle.generate(e1, [prompt], **okw)[0]
+        check_hypothesis(oracle, e1[0], prompt, out[i][j], ref, okw, tol=tb, gap=6e-2 if i8 else 2e-2,
+                         boundary=2 * tb, what=f"{tag} call {i} chunk {j}")
+        d = abs(out[i][j].no_speech_prob - ref.no_speech_prob)
+        assert d < tolerance(cfg.name, compute_type, "nsp"), (tag, i, j, d)
+
+
+def test_merged_run_large_v3_float16(lv3):
+    cfg, w = lv3
+    _merged(cfg, w, "float16")
+
+
+def test_merged_run_large_v3_int8_float16(lv3):
+    cfg, w = lv3
+    _merged(cfg, w, "int8_float16", oracle_chunks=((7, 15),))

@@ -62,7 +62,11 @@ def _check_ids(got, ref):
     while n < len(ref.sequences_ids[0]) and n < len(ref.margins) and ref.margins[n] > MARGIN:
         n += 1
     assert got.sequences_ids[0][:n] == ref.sequences_ids[0][:n], (got.sequences_ids[0], ref.sequences_ids[0], ref.margins)
-    return n, got.sequences_ids[0] == ref.sequences_ids[0]
+    same = got.sequences_ids[0] == ref.sequences_ids[0]
+    # a comparison over fewer than 4 ids proves nothing: the seeded inputs of these tests keep the oracle's margins
+    # above MARGIN for at least that long (or the whole sequence agrees anyway)
+    assert n >= 4 or same, (n, ref.margins[:4])
+    return n, same
 
 
 @pytest.mark.parametrize("timestamps", [False, True])

@@ -65,7 +65,10 @@ def test_sequential_beam_with_word_timestamps(pair):
             assert w.end >= w.start >= 0.0 and 0.0 <= w.probability <= 1.0
     n = _same_prefix(got, ref)
     print(f"sequential beam: {n}/{len(ref)} leading segments identical to the oracle-driven host run")
-    assert n >= 1                      # the first window is free of accumulated low-margin divergence
+    # the whole first window (free of accumulated low-margin divergence) and at least half of the recording; measured
+    # on the box: 12 / 12 identical
+    n_first = sum(1 for r in ref if r.seek == ref[0].seek)
+    assert n >= max(n_first, (len(ref) + 1) // 2), (n, n_first, len(ref))
     for a, b in zip(got[:n], ref[:n]):
         assert a.start == pytest.approx(b.start, abs=0.021) and a.end == pytest.approx(b.end, abs=0.021)
         assert a.avg_logprob == pytest.approx(b.avg_logprob, abs=2e-3 * max(1.0, abs(b.avg_logprob)))
