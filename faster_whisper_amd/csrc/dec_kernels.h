@@ -37,16 +37,14 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act);
-// the skinny kernel whatever the row count (launch_dec_gemm_frag hands large merged runs to the tile kernel)
+// the skinny kernel whatever the row count (launch_dec_gemm_frag hands merged runs to the GEMM-shaped kernel)
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                            int N, int K, int act);
-int launch_dec_gemm_tile(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
-                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                         int N, int K, int act);
-int launch_dec_gemm_tile_pipe(hipStream_t st, int nst, const half_t* xf, const half_t* Wf, const half_t* bias,
-                              const float* s1, const float* cf, const half_t* res, int ldr, half_t* out, int ldo,
-                              half_t* out_frag, int R, int N, int K, int act);
+// the GEMM-shaped kernel of merged runs whatever the row count, workgroup shape cfg (dec_kernels.hip); same bits
+int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
+                        const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
+                        int N, int K, int act);
 int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
                                  const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
                                  int K);

@@ -45,6 +45,57 @@ __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __re
 }
 
 // ------------------------------------------------------------------------------------
+// The decoder linear's epilogue arithmetic, PINNED operation by operation (no compiler contraction choices: explicit
+// fma where one is meant, separate roundings elsewhere).  The skinny kernel of solo runs and the GEMM-shaped kernel
+// of merged runs both end in these two functions, so that which kernel a run takes never changes a bit of its result.
+//   LNF:  y = rstd * (v - mu * s1[n]) + cf[n]     (LayerNorm folded into the weights: s1 = rowsum(W o g), cf = W b + bias)
+//   else: y = v + bias[n]
+//   then  act == 1: exact-erf GELU;   then + residual;   ONE rounding to fp16
+// ------------------------------------------------------------------------------------
+static __device__ __forceinline__ void dec_ln_stats(float sa, float sb, int K, float& mu, float& rstd) {
+#pragma clang fp contract(off)
+  const float kf = (float)K;
+  mu = sa / kf;
+  const float ex2 = sb / kf;
+  const float var = ex2 - mu * mu;
+  rstd = rsqrtf(fmaxf(var, 0.f) + 1e-5f);
+}
+template <bool LNF>
+static __device__ __forceinline__ half4_t dec_epilogue4(const floatx4 v, float mu, float rstd,
+                                                        const float* __restrict__ s1, const float* __restrict__ cf,
+                                                        const half_t* __restrict__ bias, const half_t* __restrict__ res,
+                                                        int ldr, int row, int n, int act) {
+#pragma clang fp contract(off)
+  floatx4 a4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+  half4_t b4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}, r4 = b4;
+  if (LNF) {
+    a4 = *reinterpret_cast<const floatx4*>(s1 + n);
+    c4 = *reinterpret_cast<const floatx4*>(cf + n);
+  } else if (bias) {
+    b4 = *reinterpret_cast<const half4_t*>(bias + n);
+  }
+  if (res) r4 = *reinterpret_cast<const half4_t*>(res + (size_t)row * ldr + n);
+  half4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float tv = v[e];
+    if (LNF) {
+      const float t = tv - mu * a4[e];
+      tv = rstd * t + c4[e];
+    } else if (bias) {
+      tv = tv + (float)b4[e];
+    }
+    if (act == 1) {
+      const float er = erff(tv * 0.70710678118654752440f);
+      tv = (0.5f * tv) * (1.0f + er);
+    }
+    if (res) tv = tv + (float)r4[e];
+    o[e] = (half_t)tv;
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------
 // Skinny GEMM, register-streaming form over FRAGMENT-MAJOR operands (frag_off above).
 //
 // Both the weights (permuted once at pack time) and the activations (written in this order by their
@@ -165,20 +216,11 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
         float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) { sa += red_s[w][a][i][0]; sb += red_s[w][a][i][1]; }
-        mu = sa / (float)K;
-        rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
+        dec_ln_stats(sa, sb, K, mu, rstd);
       }
       const int n = (ct0 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
-      half4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = v[e];
-        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-        else if (bias) tv += (float)bias[n + e];
-        if (act == 1) tv = gelu_erf(tv);
-        if (res) tv += (float)res[(size_t)row * ldr + n + e];
-        o[e] = (half_t)tv;
-      }
+      const floatx4 v4 = {v[0], v[1], v[2], v[3]};
+      const half4_t o = dec_epilogue4<LNF>(v4, mu, rstd, s1, cf, bias, res, ldr, row, n, act);
       if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
       if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
     }
@@ -186,257 +228,192 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// GEMM-shaped form of the decoder linear for MERGED decode runs (hundreds to 1 680 rows) — candidate, not yet
-// selected by launch_dec_gemm_frag (profiles/NOTES.md, "Next").  The skinny kernel above moves every x / W
-// fragment from L2 once per 32 x 32 outputs; here a workgroup owns 128 rows x 64 columns and stages the fragments
-// ONCE in LDS for its 8 waves (L2 -> LDS DMA, 1 KB pieces = whole fragments, which are contiguous in the
-// fragment-major layout), so 2.7x fewer bytes cross L2 per output.
-//   * 12 tiles (8 row tiles of x, 4 column tiles of W) x DGT_KC k-steps = 24 KB per stage, 2 stages: 3 workgroups
-//     per CU; every wave issues 3 pieces per chunk, one counted wait (vmcnt(3)) + barrier per chunk.
-//   * wave (wr = w >> 1, wc = w & 1) owns row tiles 2wr, 2wr+1 x column tiles 2wc, 2wc+1 over the WHOLE K.
-//   * BIT-IDENTICAL to dec_gemm_frag_kernel<S waves>: that kernel cuts K into S slices of consecutive k-steps, runs
-//     one MFMA chain per slice from a zero accumulator and adds the slice partials in slice order starting from
-//     0.0f (likewise the LayerNorm statistics).  The same chains and the same additions are made here by one wave:
-//     at every slice boundary  total += acc; acc = 0.  So a merged run that takes this kernel returns exactly what
-//     a solo run through the skinny kernel returns (tests/test_gpu_kernels.py::test_dec_linear_tile_bit_identical).
+// GEMM-shaped form of the decoder linear for MERGED decode runs (hundreds to 2 000 rows).  The skinny kernel above
+// moves every x / W fragment from L2 once per 32 x 32 outputs and runs at ~360 TFLOP/s at 1 680 rows; at those row
+// counts the linears are ordinary MFMA-bound GEMMs.  Here:
+//   * one wave owns 64 rows x 64 columns (4 x 4 tiles: every fragment read from LDS feeds 4 MFMAs); a workgroup is
+//     WM x WN waves = (64 WM) rows x (64 WN) columns;
+//   * operands are FRAGMENT-MAJOR in HBM, so a k-step of the workgroup tile is 4 (WM + WN) contiguous 1 KB pieces: one
+//     global_load_lds per piece (a wave instruction moves exactly one MFMA fragment), the LDS image is the fragment
+//     itself and every ds_read_b128 is lane-linear: no swizzle, no bank conflicts;
+//   * ring of NST stages of KC k-steps, ONE barrier per stage: wait (counted vmcnt, NST - 2 stages stay in flight)
+//     -> barrier -> refill the stage read last -> 16 KC MFMAs per wave;
+//   * BIT-IDENTICAL to dec_gemm_frag_kernel<S waves>: that kernel cuts K into S slices of consecutive k-steps, runs one
+//     MFMA chain per slice from a zero accumulator and adds the slice partials in slice order starting from 0.0f
+//     (likewise the LayerNorm statistics).  The same chains and the same additions are made here by one wave — at a
+//     slice boundary  total += acc; acc = 0  — and both kernels share the pinned epilogue (dec_epilogue4).  So a
+//     merged run returns exactly what each caller's solo run returns (tests/test_gpu_kernels.py::
+//     test_dec_linear_big_bit_identical, tests/test_gpu_full_size.py::test_merged_run_*).
 // ------------------------------------------------------------------------------------
-#define DGT_KC 2
-#define DGT_STAGE_BYTES (12 * DGT_KC * 1024)
+template <int N_>
+static __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
 // workgroup barrier without the fence of __syncthreads() (which would drain the DMA queue: vmcnt(0)); the counted
 // vmcnt before it is what orders the staged bytes, as in gemm.hip
-#define DGT_BARRIER()                      \
+#define DGB_BARRIER()                      \
   do {                                     \
     asm volatile("" ::: "memory");         \
     __builtin_amdgcn_s_barrier();          \
     asm volatile("" ::: "memory");         \
   } while (0)
-template <bool LNF, int S>
-__global__ __launch_bounds__(512) void dec_gemm_tile_kernel(
+
+template <bool LNF, int S, int WM, int WN, int KC, int NST, int PF>
+__global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
-    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
-  __shared__ __attribute__((aligned(16))) char stage[2][DGT_STAGE_BYTES];
+    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act, int nNt) {
+  constexpr int NW = WM * WN;
+  constexpr int PX = 4 * WM, PW = 4 * WN, PCS = PX + PW;   // fragments (1 KB pieces) of one k-step: x row tiles, W column tiles
+  static_assert((PCS * KC) % NW == 0, "pieces of a stage must divide over the waves");
+  constexpr int PPW = PCS * KC / NW;                       // pieces a wave issues per stage
+  constexpr int STAGE_BYTES = PCS * KC * 1024;
+  static_assert(NST >= 2 && NST <= 9, "ring depth");
+  constexpr int GRP = PPW + (PF > 0 ? 1 : 0);             // memory instructions a wave issues per stage
+  static_assert(8 * PPW <= 64, "one touch instruction covers the wave's pieces of a stage");
+  // NST stages + (PF > 0) 256 B per wave that the L2 touches land in (the only LDS object of the kernel)
+  extern __shared__ __attribute__((aligned(16))) char dgb_smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int ct0 = blockIdx.x * 4, rt0 = blockIdx.y * 8;
+  const int wm = wave / WN, wn = wave % WN;
+  // consecutive tiles run on one XCD (xcd_remap) and share the W column tile — the operand that is cold in HBM (the
+  // weights of a step are 1.5 GB: never cached from one use to the next) is fetched once per XCD, its row-panel
+  // siblings hit that XCD's L2
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nMt = gridDim.x / nNt;
+  const int nt = bid / nMt, mt = bid - nt * nMt;
+  const int rt0 = mt * PX, ct0 = nt * PW;
   const int n_rt = (R + 15) >> 4;
   const int KS = K >> 5;
-  const int per = KS / S;                 // k-steps per slice (the launcher guarantees KS % S == 0, per % DGT_KC == 0)
-  const int nch = KS / DGT_KC;            // chunks
-  const int ch_per_slice = per / DGT_KC;
+  const int per = KS / S;                 // k-steps per slice (the launcher guarantees KS % S == 0, per % KC == 0)
+  const int nch = KS / KC;                // stages' worth of K
+  const int ch_per_slice = per / KC;
 
-  // staging: piece p = tile * DGT_KC + ks (tiles 0-7: x row tiles, 8-11: W column tiles); wave w issues pieces 3w..3w+2
-  const char* src[3];
+  // staging: piece p of a stage = (tile t = p / KC, k-step p % KC); tiles 0 .. PX-1 are x row tiles, PX .. PCS-1 W
+  // column tiles; wave w issues pieces w * PPW .. + PPW - 1
+  const char* src[PPW];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int p = wave * 3 + q;
-    const int t = p / DGT_KC, ks = p % DGT_KC;
-    if (t < 8) {
+  for (int q = 0; q < PPW; ++q) {
+    const int p = wave * PPW + q;
+    const int t = p / KC, ks = p % KC;
+    if (t < PX) {
       int rt = rt0 + t;
       if (rt > n_rt - 1) rt = n_rt - 1;   // a missing row tile re-reads the last one; its result is dropped
       src[q] = reinterpret_cast<const char*>(xf) + (((size_t)rt * KS + ks) * 64 + lane) * 16;
     } else {
-      src[q] = reinterpret_cast<const char*>(Wf) + (((size_t)(ct0 + t - 8) * KS + ks) * 64 + lane) * 16;
+      int ct = ct0 + t - PX;
+      if (ct > (N >> 4) - 1) ct = (N >> 4) - 1;   // a missing column tile re-reads the last one; never stored
+      src[q] = reinterpret_cast<const char*>(Wf) + (((size_t)ct * KS + ks) * 64 + lane) * 16;
     }
   }
-  auto issue = [&](int c) {   // chunk c -> stage c & 1
-    char* dst = stage[c & 1] + wave * 3 * 1024;
-    const size_t koff = (size_t)c * DGT_KC * 1024;   // DGT_KC k-steps further along every tile's fragment run
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + koff),
-                                       (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-  };
-
-  floatx4 acc[2][2], tot[2][2];
-  float rs[2], rq[2], sa[2], sb[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    rs[a] = 0.f; rq[a] = 0.f; sa[a] = 0.f; sb[a] = 0.f;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
-  }
-
-  issue(0);
-  for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) {
-      issue(c + 1);
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // chunk c has landed (this wave's pieces); c + 1 stays in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    DGT_BARRIER();                                       // ... and everybody else's
-    const char* st = stage[c & 1];
-#pragma unroll
-    for (int ks = 0; ks < DGT_KC; ++ks) {
-      half8_t xv[2], wv[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-        xv[a] = *reinterpret_cast<const half8_t*>(st + (((wr * 2 + a) * DGT_KC + ks) * 64 + lane) * 16);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        wv[b] = *reinterpret_cast<const half8_t*>(st + (((8 + wc * 2 + b) * DGT_KC + ks) * 64 + lane) * 16);
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[b], xv[a], acc[a][b], 0, 0, 0);
-        if (LNF) {
-          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const half2_t h2 = {xv[a][2 * e], xv[a][2 * e + 1]};
-            rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
-            rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
-          }
-        }
-      }
-    }
-    if ((c + 1) % ch_per_slice == 0) {   // slice boundary: the skinny kernel's fixed-order reduction, one term at a time
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        if (LNF) {
-          float pa = rs[a], pb = rq[a];
-          pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
-          pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
-          sa[a] += pa; sb[a] += pb;
-          rs[a] = 0.f; rq[a] = 0.f;
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tot[a][b][e] += acc[a][b][e];
-          acc[a][b] = floatx4{0, 0, 0, 0};
-        }
-      }
-    }
-    DGT_BARRIER();   // stage c & 1 is refilled by the issue of the next iteration (its reads are in registers: the
-                     // MFMAs above consumed them)
-  }
-
-  // epilogue: the skinny kernel's, straight from registers
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = (rt0 + wr * 2 + a) * 16 + i;
-    if (row >= R) continue;
-    float mu = 0.f, rstd = 1.f;
-    if (LNF) {
-      mu = sa[a] / (float)K;
-      rstd = rsqrtf(fmaxf(sb[a] / (float)K - mu * mu, 0.f) + 1e-5f);
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int n = (ct0 + wc * 2 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
-      half4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = tot[a][b][e];
-        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-        else if (bias) tv += (float)bias[n + e];
-        if (act == 1) tv = gelu_erf(tv);
-        if (res) tv += (float)res[(size_t)row * ldr + n + e];
-        o[e] = (half_t)tv;
-      }
-      if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
-      if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
-    }
-  }
-}
-
-// NST-stage form of the kernel above: NST - 1 chunks in flight per workgroup, ONE barrier per chunk (wait for chunk c,
-// barrier, refill the stage that chunk c - 1 was read from, compute chunk c).  Same arithmetic, same bits.
-template <bool LNF, int S, int NST>
-__global__ __launch_bounds__(512) void dec_gemm_tile_pipe_kernel(
-    const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
-    const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
-    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
-  __shared__ __attribute__((aligned(16))) char stage[NST][DGT_STAGE_BYTES];
-  static_assert(NST >= 3 && NST <= 4, "vmcnt immediates below cover 1 or 2 younger chunks");
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = lane & 15, g = lane >> 4;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int ct0 = blockIdx.x * 4, rt0 = blockIdx.y * 8;
-  const int n_rt = (R + 15) >> 4;
-  const int KS = K >> 5;
-  const int per = KS / S;                 // k-steps per slice (the launcher guarantees KS % S == 0, per % DGT_KC == 0)
-  const int nch = KS / DGT_KC;            // chunks
-  const int ch_per_slice = per / DGT_KC;
-
-  // staging: piece p = tile * DGT_KC + ks (tiles 0-7: x row tiles, 8-11: W column tiles); wave w issues pieces 3w..3w+2
-  const char* src[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int p = wave * 3 + q;
-    const int t = p / DGT_KC, ks = p % DGT_KC;
-    if (t < 8) {
+  // L2 touch (PF > 0): the ring holds NST - 1 stages = a few tens of KB in flight per CU, which hides an L2 hit but
+  // not an HBM (W) or Infinity-Cache (x, written by the previous kernel on other XCDs) miss.  So every stage's DMA
+  // group carries one more instruction that pulls the lines of the stage PF further on into this XCD's L2: a 4-byte
+  // LDS-DMA per lane, lane l = (piece l / 8 of this wave, 128-byte line l % 8), landing in a 256-byte dump area.
+  // Same instruction kind as the pieces: the counted vmcnt protocol just counts GRP = PPW + 1 per stage.
+  const char* tsrc = nullptr;
+  if (PF > 0) {
+    const int tl = lane % (8 * PPW);
+    const int p = wave * PPW + (tl >> 3);
+    const int t = p / KC, ks = p % KC;
+    if (t < PX) {
       int rt = rt0 + t;
-      if (rt > n_rt - 1) rt = n_rt - 1;   // a missing row tile re-reads the last one; its result is dropped
-      src[q] = reinterpret_cast<const char*>(xf) + (((size_t)rt * KS + ks) * 64 + lane) * 16;
+      if (rt > n_rt - 1) rt = n_rt - 1;
+      tsrc = reinterpret_cast<const char*>(xf) + ((size_t)rt * KS + ks) * 1024 + (tl & 7) * 128;
     } else {
-      src[q] = reinterpret_cast<const char*>(Wf) + (((size_t)(ct0 + t - 8) * KS + ks) * 64 + lane) * 16;
+      int ct = ct0 + t - PX;
+      if (ct > (N >> 4) - 1) ct = (N >> 4) - 1;
+      tsrc = reinterpret_cast<const char*>(Wf) + ((size_t)ct * KS + ks) * 1024 + (tl & 7) * 128;
     }
   }
-  auto issue = [&](int c) {   // chunk c -> stage c % NST
-    char* dst = stage[c % NST] + wave * 3 * 1024;
-    const size_t koff = (size_t)c * DGT_KC * 1024;   // DGT_KC k-steps further along every tile's fragment run
+  char* const dump = dgb_smem + NST * STAGE_BYTES + wave * 256;
+  auto touch = [&](int c) {               // lines of K stage c (clamped: a touch past the end repeats the last stage)
+    if (PF > 0) {
+      const int cc = c < nch ? c : nch - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + (size_t)cc * KC * 1024),
+                                       (__attribute__((address_space(3))) void*)dump, 4, 0, 0);
+    }
+  };
+  auto issue = [&](int c, int slot) {   // K stage c -> ring slot (+ the touch of stage c + PF)
+    char* dst = dgb_smem + slot * STAGE_BYTES + wave * PPW * 1024;
+    const size_t koff = (size_t)c * KC * 1024;   // KC k-steps further along every tile's fragment run
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < PPW; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + koff),
                                        (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+    touch(c + PF);
   };
 
-  floatx4 acc[2][2], tot[2][2];
-  float rs[2], rq[2], sa[2], sb[2];
+  floatx4 acc[4][4], tot[4][4];
+  float rs[4], rq[4], sa[4], sb[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < 4; ++a) {
     rs[a] = 0.f; rq[a] = 0.f; sa[a] = 0.f; sb[a] = 0.f;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
+    for (int b = 0; b < 4; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
   }
 
+  if (PF > 0) {
+    // stages 0 .. PF - 1 are touched up front (older than every piece, they retire first: the counts below hold)
+    for (int c0 = 0; c0 < PF; ++c0) touch(c0);
+  }
 #pragma unroll
   for (int c0 = 0; c0 < NST - 1; ++c0)
-    if (c0 < nch) issue(c0);
+    if (c0 < nch) issue(c0, c0);
+  int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
+  int to_slice = ch_per_slice;
   for (int c = 0; c < nch; ++c) {
-    // chunks c .. min(c + NST - 2, nch - 1) are in flight: wait until only the younger ones are
+    // stages c .. min(c + NST - 2, nch - 1) are in flight: wait until only the younger ones are
     const int younger = (nch - 1 - c) < (NST - 2) ? (nch - 1 - c) : (NST - 2);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    DGT_BARRIER();   // chunk c has landed for every wave, and every wave has finished computing chunk c - 1 ...
-    if (c + NST - 1 < nch) issue(c + NST - 1);   // ... whose stage is the one refilled now
-    const char* st = stage[c % NST];
+    switch (younger) {
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<1 * GRP>(); break;
+      case 2: wait_vmcnt<2 * GRP>(); break;
+      case 3: wait_vmcnt<3 * GRP>(); break;
+      case 4: wait_vmcnt<4 * GRP>(); break;
+      case 5: wait_vmcnt<5 * GRP>(); break;
+      case 6: wait_vmcnt<6 * GRP>(); break;
+      default: wait_vmcnt<7 * GRP>(); break;
+    }
+    DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
+    if (c + NST - 1 < nch) issue(c + NST - 1, fill);   // ... whose slot is the one refilled now
+    const char* st = dgb_smem + slot * STAGE_BYTES;
+    // every fragment of the stage is requested up front (16 KC bytes per lane in flight), the MFMAs then wait with
+    // counted lgkmcnt for exactly the operands they need: the LDS latency is paid once per stage, under the MFMAs
+    half8_t xv[KC][4], wv[KC][4];
 #pragma unroll
-    for (int ks = 0; ks < DGT_KC; ++ks) {
-      half8_t xv[2], wv[2];
+    for (int ks = 0; ks < KC; ++ks) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-        xv[a] = *reinterpret_cast<const half8_t*>(st + (((wr * 2 + a) * DGT_KC + ks) * 64 + lane) * 16);
+      for (int b = 0; b < 4; ++b)
+        wv[ks][b] = *reinterpret_cast<const half8_t*>(st + (((PX + wn * 4 + b) * KC + ks) * 64 + lane) * 16);
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-        wv[b] = *reinterpret_cast<const half8_t*>(st + (((8 + wc * 2 + b) * DGT_KC + ks) * 64 + lane) * 16);
+      for (int a = 0; a < 4; ++a)
+        xv[ks][a] = *reinterpret_cast<const half8_t*>(st + (((wm * 4 + a) * KC + ks) * 64 + lane) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+    for (int ks = 0; ks < KC; ++ks) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[b], xv[a], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][b], xv[ks][a], acc[a][b], 0, 0, 0);
         if (LNF) {
           const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const half2_t h2 = {xv[a][2 * e], xv[a][2 * e + 1]};
+            const half2_t h2 = {xv[ks][a][2 * e], xv[ks][a][2 * e + 1]};
             rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
             rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
           }
         }
       }
     }
-    if ((c + 1) % ch_per_slice == 0) {   // slice boundary: the skinny kernel's fixed-order reduction, one term at a time
+    if (--to_slice == 0) {   // slice boundary: the skinny kernel's fixed-order reduction, one term at a time
+      to_slice = ch_per_slice;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+      for (int a = 0; a < 4; ++a) {
         if (LNF) {
           float pa = rs[a], pb = rq[a];
           pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
@@ -445,38 +422,29 @@ __global__ __launch_bounds__(512) void dec_gemm_tile_pipe_kernel(
           rs[a] = 0.f; rq[a] = 0.f;
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 4; ++b) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) tot[a][b][e] += acc[a][b][e];
           acc[a][b] = floatx4{0, 0, 0, 0};
         }
       }
     }
+    fill = slot;
+    slot = (slot + 1 == NST) ? 0 : slot + 1;
   }
 
-  // epilogue: the skinny kernel's, straight from registers
+  // epilogue: the skinny kernel's (dec_epilogue4), straight from registers
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = (rt0 + wr * 2 + a) * 16 + i;
+  for (int a = 0; a < 4; ++a) {
+    const int row = (rt0 + wm * 4 + a) * 16 + i;
     if (row >= R) continue;
     float mu = 0.f, rstd = 1.f;
-    if (LNF) {
-      mu = sa[a] / (float)K;
-      rstd = rsqrtf(fmaxf(sb[a] / (float)K - mu * mu, 0.f) + 1e-5f);
-    }
+    if (LNF) dec_ln_stats(sa[a], sb[a], K, mu, rstd);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int n = (ct0 + wc * 2 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
-      half4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = tot[a][b][e];
-        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-        else if (bias) tv += (float)bias[n + e];
-        if (act == 1) tv = gelu_erf(tv);
-        if (res) tv += (float)res[(size_t)row * ldr + n + e];
-        o[e] = (half_t)tv;
-      }
+    for (int b = 0; b < 4; ++b) {
+      const int n = (ct0 + wn * 4 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
+      if (n >= N) continue;
+      const half4_t o = dec_epilogue4<LNF>(tot[a][b], mu, rstd, s1, cf, bias, res, ldr, row, n, act);
       if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
       if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
     }
@@ -1421,6 +1389,11 @@ __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __re
 
 namespace fwd {
 
+// row count from which a decode run takes the GEMM-shaped decoder linear, and its workgroup shape
+// (profiles/r03_dec_linear_bench.txt)
+#define DEC_BIG_MIN_ROWS 512
+#define DEC_BIG_CFG 0
+
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d, const int* d_step, int pos_fixed, int P) {
   dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, xfrag, d, d_step, pos_fixed, P);
@@ -1439,39 +1412,52 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
                                                                K, act);
 }
 
-// GEMM-shaped candidate for merged runs (see dec_gemm_tile_kernel): -1 when the shape does not fit its slicing
-int launch_dec_gemm_tile(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
-                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                         int N, int K, int act) {
-  if (K % 32 != 0 || N % 64 != 0 || R < 1) return -1;
-  const int S = K >= 2560 ? 8 : 4;   // the slice count of launch_dec_gemm_frag's instantiation for this K
+// GEMM-shaped kernel of merged runs (dec_gemm_big_kernel), workgroup shape `cfg`; -1 when the shape does not fit.
+//   cfg 0: 2 x 2 waves (128 x 128), 1 k-step per stage, 4 stages (64 KB: two workgroups per CU), L2 touch 10 stages ahead
+//   cfg 1: 4 x 2 waves (256 rows x 128 columns), 2 k-steps per stage, 3 stages (144 KB), touch 5 stages ahead
+//   cfg 2: 2 x 2 waves, 1 k-step per stage, 4 stages, no touch
+//   cfg 3: 2 x 2 waves, 1 k-step per stage, 9 stages (144 KB: one workgroup per CU, 128 KB in flight), no touch
+//   cfg 4: 2 x 2 waves, 1 k-step per stage, 4 stages, touch 20 stages ahead
+//   cfg 5: 2 x 4 waves (128 rows x 256 columns), 2 k-steps per stage, 3 stages, touch 5 stages ahead
+template <bool LNF, int S, int WM, int WN, int KC, int NST, int PF>
+static void big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
+                   const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
+  constexpr int lds = 4 * (WM + WN) * KC * 1024 * NST + (PF > 0 ? WM * WN * 256 : 0);
+  static bool attr_set = false;   // (per instantiation)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, KC, NST, PF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int nMt = ((R + 15) / 16 + 4 * WM - 1) / (4 * WM), nNt = (N / 16 + 4 * WN - 1) / (4 * WN);
+  dec_gemm_big_kernel<LNF, S, WM, WN, KC, NST, PF><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out,
+                                                                                      ldo, out_frag, R, N, K, act, nNt);
+}
+template <int WM, int WN, int KC, int NST, int PF>
+static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
+                   const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
+  if (K % 32 != 0 || N % 16 != 0 || R < 1) return -1;
+  const int S = K >= 2560 ? 8 : 4;   // the slice count of launch_dec_gemm_skinny's instantiation for this K
   const int KS = K / 32;
-  if (KS % S != 0 || (KS / S) % DGT_KC != 0) return -1;
-  const dim3 grid(N / 64, ((R + 15) / 16 + 7) / 8);
-#define DGT(LNF_, S_) dec_gemm_tile_kernel<LNF_, S_><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, \
-                                                                          out_frag, R, N, K, act)
-  if (s1) { if (S == 8) DGT(true, 8); else DGT(true, 4); }
-  else { if (S == 8) DGT(false, 8); else DGT(false, 4); }
-#undef DGT
+  if (KS % S != 0 || (KS / S) % KC != 0) return -1;
+#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, KC, NST, PF>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
+  if (s1) { if (S == 8) DGB(true, 8); else DGB(true, 4); }
+  else { if (S == 8) DGB(false, 8); else DGB(false, 4); }
+#undef DGB
   return 0;
 }
-// the NST-stage form (nst = 3 or 4)
-int launch_dec_gemm_tile_pipe(hipStream_t st, int nst, const half_t* xf, const half_t* Wf, const half_t* bias,
-                              const float* s1, const float* cf, const half_t* res, int ldr, half_t* out, int ldo,
-                              half_t* out_frag, int R, int N, int K, int act) {
-  if (K % 32 != 0 || N % 64 != 0 || R < 1 || (nst != 3 && nst != 4)) return -1;
-  const int S = K >= 2560 ? 8 : 4;
-  const int KS = K / 32;
-  if (KS % S != 0 || (KS / S) % DGT_KC != 0) return -1;
-  const dim3 grid(N / 64, ((R + 15) / 16 + 7) / 8);
-#define DGP(LNF_, S_, NST_) dec_gemm_tile_pipe_kernel<LNF_, S_, NST_><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, \
-                                                                                        ldo, out_frag, R, N, K, act)
-#define DGP2(LNF_, S_) do { if (nst == 3) DGP(LNF_, S_, 3); else DGP(LNF_, S_, 4); } while (0)
-  if (s1) { if (S == 8) DGP2(true, 8); else DGP2(true, 4); }
-  else { if (S == 8) DGP2(false, 8); else DGP2(false, 4); }
-#undef DGP2
-#undef DGP
-  return 0;
+int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
+                        const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
+                        int N, int K, int act) {
+  switch (cfg) {
+    case 0: return big_cfg<2, 2, 1, 4, 10>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 1: return big_cfg<4, 2, 2, 3, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 2: return big_cfg<2, 2, 1, 4, 0>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 3: return big_cfg<2, 2, 1, 9, 0>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 4: return big_cfg<2, 2, 1, 4, 20>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 5: return big_cfg<2, 4, 2, 3, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    default: return -1;
+  }
 }
 
 // tile-shape experiments of profiles/dec_linear_bench.py (fw_bench_dec_linear): variant -> instantiation
@@ -1501,11 +1487,9 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 7: frag_variant<8, 2, 4, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 8: frag_variant<8, 8, 2, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 9: frag_variant<4, 4, 4, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
-    case 10: return launch_dec_gemm_tile(st, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr, nullptr,
-                                         0, out, N, nullptr, R, N, K, 0);
-    case 11: case 12:
-      return launch_dec_gemm_tile_pipe(st, variant - 8, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr,
-                                       lnf ? cf : nullptr, nullptr, 0, out, N, nullptr, R, N, K, 0);
+    case 10: case 11: case 12: case 13: case 14: case 15:
+      return launch_dec_gemm_big(st, variant - 10, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr,
+                                 nullptr, 0, out, N, nullptr, R, N, K, 0);
     default: return -1;
   }
   return 0;
@@ -1518,9 +1502,9 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act) {
-  // The GEMM-shaped kernel (dec_gemm_tile_kernel, bit-identical by construction and by test) is NOT selected: handing
-  // it the runs of >= 1 024 rows measured 2 742x against 2 760-2 820x without it (isolated it is 11 % faster per layer
-  // at 1 680 rows, slower below ~1 000: profiles/NOTES.md).  It stays as the starting point of the next round.
+  // merged runs: the GEMM-shaped kernel (bit-identical by construction and by test); solo runs: the skinny kernel
+  if (R >= DEC_BIG_MIN_ROWS && launch_dec_gemm_big(st, DEC_BIG_CFG, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
+    return 0;
   return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
 }
 

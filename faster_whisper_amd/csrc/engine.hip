@@ -1649,15 +1649,12 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
     for (int n = 0; n < N; ++n) tmp[n] = f32_to_f16_bits(bias[n]);
     if ((rc = up(tmp.data(), (size_t)N * 2, (void**)&d_bias))) { cleanup(); return rc; }
   }
-  // use_int8 == 2: the GEMM-shaped candidate for merged runs (dec_gemm_tile_kernel), same operands
-  // (use_int8 == 3 / 4: its 3- / 4-stage form)
+  // use_int8 >= 10: the GEMM-shaped kernel of merged runs (dec_gemm_big_kernel), workgroup shape use_int8 - 10,
+  // whatever the row count; 5: the skinny kernel whatever the row count (the reference of the bit-identity test)
   const int lr =
-      use_int8 == 2 ? fwd::launch_dec_gemm_tile(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
-      : (use_int8 == 3 || use_int8 == 4)
-          ? fwd::launch_dec_gemm_tile_pipe(st, use_int8, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
-      : use_int8 == 5   // the skinny kernel whatever the row count (the reference of the bit-identity test)
-          ? fwd::launch_dec_gemm_skinny(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
-          : fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act);
+      use_int8 >= 10 ? fwd::launch_dec_gemm_big(st, use_int8 - 10, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
+      : use_int8 == 5 ? fwd::launch_dec_gemm_skinny(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
+                      : fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act);
   if (lr != 0) {
     cleanup();
     set_error("decoder linear: unsupported shape R=%d N=%d K=%d", R, N, K);
@@ -1734,8 +1731,13 @@ int32_t fw_bench_dec_linear(fw_model* fm, int32_t R, int32_t N, int32_t K, int32
     cleanup();
     return rc;
   }
-  FW_HIP(hipMemset(dW, 0x11, wn * copies * 2));
-  FW_HIP(hipMemset(dX, 0x22, rp * K * 2));
+  {   // pseudo-random operands in [-1, 1) (constant fills clock the chip up: MI355X_MICROARCH.md, DVFS)
+    std::vector<uint16_t> h(std::max(wn, rp * (size_t)K));
+    uint32_t sd = 2463534242u;
+    for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = f32_to_f16_bits(((int)(sd >> 16) % 2001 - 1000) * 1e-3f); }
+    for (int c = 0; c < copies; ++c) FW_HIP(hipMemcpy(dW + (size_t)c * wn, h.data(), wn * 2, hipMemcpyHostToDevice));
+    FW_HIP(hipMemcpy(dX, h.data(), rp * K * 2, hipMemcpyHostToDevice));
+  }
   FW_HIP(hipMemset(dB, 0, (size_t)N * 2));
   FW_HIP(hipMemset(dS, 0, (size_t)N * 4));
   FW_HIP(hipMemset(dC, 0, (size_t)N * 4));
@@ -1764,6 +1766,12 @@ int32_t fw_bench_dec_linear(fw_model* fm, int32_t R, int32_t N, int32_t K, int32
 
 // measurement hook (profiles/gemm_bench.py): the encoder GEMM on device-resident pseudo-random operands,
 // `iters` launches between two events.  lda = K + a_pad, ldw = K + w_pad elements (stride experiments).
+int32_t fw_test_set_gemm_pipe(int32_t pipe) {
+  const int old = fwk::get_gemm_pipe();
+  fwk::set_gemm_pipe(pipe);
+  return old;
+}
+
 int32_t fw_bench_gemm(fw_model* fm, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
                       int32_t trans, int32_t iters, float* ms_out) {
   FW_CHECK_ARG(fm && ms_out && M > 0 && N > 0 && K > 0 && batch > 0 && iters > 0, "bad argument");

@@ -18,8 +18,8 @@ int32_t fw_test_gemm(fw_model* m, const float* A, const float* W, const float* b
  * given, GELU when act = 1, residual added last): x [R][K], W [N][K], bias [N] | NULL, res [R][N] | NULL ->
  * out [R][N] (row-major result) and out_from_frag [R][N] (the fragment-major copy the next linear reads, un-permuted
  * on the host).  use_int8 = 0: what a decode step launches for this row count; 1: the int8_float16 form (needs an
- * int8_float16 model; ln must be NULL); 2 / 3 / 4: the GEMM-shaped kernel of large merged runs (dec_gemm_tile_kernel,
- * 2-, 3-, 4-stage forms) whatever the row count; 5: the skinny kernel whatever the row count.  0, 2-5 return the same bits. */
+ * int8_float16 model; ln must be NULL); 5: the skinny kernel whatever the row count; 10 + cfg: the GEMM-shaped kernel of
+ * merged runs (dec_gemm_big_kernel) with workgroup shape cfg, whatever the row count.  0, 5, 10.. return the same bits. */
 int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const float* bias, const float* ln_g,
                            const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
                            int32_t use_int8, float* out, float* out_from_frag);
@@ -37,10 +37,14 @@ int32_t fw_test_logits_rules(fw_model* m, const float* logits, int32_t R, const 
 /* measurement hook (profiles/gemm_bench.py): average milliseconds of one launch of the "many rows" GEMM
  * C[batch][M][N] = A[batch][M][K] W[N][K]^T on device-resident pseudo-random operands (fp16, or int8 on an
  * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
+/* K-loop form of the many-rows GEMM (csrc/gemm.hip): 0 = two staggered load / compute wave groups, 1 = one
+ * software-pipelined stream per wave.  Returns the previous setting.  Process-wide; for A/B measurement and for the
+ * tests that run the kernel's parity cases in both forms. */
+int32_t fw_test_set_gemm_pipe(int32_t pipe);
 int32_t fw_bench_gemm(fw_model* m, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
                       int32_t trans, int32_t iters, float* ms_out);
 /* micro-benchmark of the decoder linear kernel (dec_gemm_frag_kernel) for a tile-shape `variant` (dec_kernels.hip:
- * launch_dec_gemm_frag_variant; 0 / 1 = the product's) over a rotating weight set larger than the caches:
+ * launch_dec_gemm_frag_variant; 0 / 1 = the product's skinny kernel, 10 + cfg = the GEMM-shaped kernel of merged runs) over a rotating weight set larger than the caches:
  * mean microseconds per launch of a [R] x [N][K] linear (lnf = LayerNorm-folded form). */
 int32_t fw_bench_dec_linear(fw_model* m, int32_t R, int32_t N, int32_t K, int32_t lnf, int32_t variant, int32_t iters,
                             float* us_out);

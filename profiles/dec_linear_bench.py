@@ -10,8 +10,9 @@ from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # n
 
 VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)", 2: "8w 4x2 ch3", 3: "8w 4x2 ch4",
             4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2",
-            10: "LDS-shared 128x64 tile, 2 stages", 11: "LDS-shared 128x64 tile, 3 stages",
-            12: "LDS-shared 128x64 tile, 4 stages"}
+            10: "big 2x2 128x128 KC1x4 touch+10", 11: "big 4x2 256x128 KC2x3 touch+5",
+            12: "big 2x2 128x128 KC1x4 no touch", 13: "big 2x2 128x128 KC1x9 (1 WG/CU)",
+            14: "big 2x2 128x128 KC1x4 touch+20", 15: "big 2x4 128x256 KC2x3 touch+5"}
 if os.environ.get("DLB_VARIANTS"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["DLB_VARIANTS"].split(",")}
 SHAPES = [("qkv", 3840, 1280, 1), ("dxd", 1280, 1280, 0), ("ffn1", 5120, 1280, 1), ("ffn2", 1280, 5120, 0)]
@@ -26,13 +27,15 @@ def main():
     rows = [int(a) for a in sys.argv[1:]] or [80, 320, 640]
     for R in rows:
         print(f"R = {R}")
-        print("  %-30s" % "variant" + "".join("%10s" % s[0] for s in SHAPES) + "   layer (qkv + 3 dxd + ffn1 + ffn2)")
+        print("  %-38s" % "variant" + "".join("%10s" % s[0] for s in SHAPES) + "   layer (qkv + 3 dxd + ffn1 + ffn2)   TFLOP/s")
         for v, name in VARIANTS.items():
             t = []
             for _, N, K, lnf in SHAPES:
                 _lib.check(m._lib.fw_bench_dec_linear(h, R, N, K, lnf, v, 400, C.byref(us)))
                 t.append(us.value)
-            print("  %-30s" % name + "".join("%10.2f" % x for x in t) + "   %8.1f" % (t[0] + 3 * t[1] + t[2] + t[3]), flush=True)
+            layer = t[0] + 3 * t[1] + t[2] + t[3]
+            flop = 2.0 * R * sum(n * k * (3 if nm == "dxd" else 1) for nm, n, k, _ in SHAPES)
+            print("  %-38s" % name + "".join("%10.2f" % x for x in t) + "   %8.1f   %8.0f" % (layer, flop / layer / 1e6), flush=True)
 
 
 if __name__ == "__main__":

@@ -101,7 +101,7 @@ def factory(args, cfg, rank, world, local_rank):
 
 
 out = bench.main(["--gpus", os.environ["WORLD_SIZE"], "--model", "micro", "--batch", "4", "--beam", "5", "--steps", "6",
-                  "--warmup", "1", "--workers", "2", "--new-tokens", "12", "--pipeline-chunks", "11",
+                  "--warmup", "1", "--workers", "2", "--new-tokens", "12", "--pipeline-chunks", "11", "--sharded-chunks", "11",
                   "--no-cpu-baseline"], backend_factory=factory, dist_backend="gloo")
 if int(os.environ["RANK"]) != 0:
     print("RANK_DONE", flush=True)

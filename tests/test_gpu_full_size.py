@@ -42,16 +42,20 @@ FP16_ORDER = "fp16 evaluation-order noise of a 32 + 32 layer model (CPU-measured
 INT8_CODES = ("engine and oracle quantise activations that differ by fp16 rounding; flipped int8 codes accumulate over "
               "2 x 32 quantised blocks (every int8 GEMM alone is bit-exact: tests/test_gpu_int8.py)")
 EXCEPTIONS = {
-    ("large-v3 float16", "lang"): (6e-3, 2.3e-3, FP16_ORDER),
-    ("large-v3 float16", "align"): (5e-3, 1.6e-3, FP16_ORDER),
-    ("distil-large-v3 float16", "lang"): (2e-3, 1.1e-3, FP16_ORDER + " (32-layer encoder feeding a softmax over 100 ids)"),
-    ("distil-large-v3 float16", "align"): (2e-3, 1.2e-3, FP16_ORDER),
+    # per-token figure of an 8-step teacher-forced sum: one near-tied token (p ~ 0.5) turns fp16 logit noise of 1e-2 into
+    # 1e-2 of log-prob; seen between 4e-5 and 2.1e-3 from chunk to chunk and build to build (the 48-step beam scores
+    # below, which average over more tokens, stay within the north star: 2.0e-4 / 2.6e-4)
+    ("large-v3 float16", "tf"): (3e-3, 1.5e-3, FP16_ORDER),
+    ("large-v3 float16", "lang"): (4e-3, 1.5e-3, FP16_ORDER),
+    ("large-v3 float16", "align"): (4e-3, 2.0e-3, FP16_ORDER),
     ("large-v3 int8_float16", "tf"): (2e-2, 1.0e-2, INT8_CODES),
-    ("large-v3 int8_float16", "beam"): (4e-2, 3.2e-2, INT8_CODES),
-    ("large-v3 int8_float16", "nsp"): (1e-2, 2.0e-3, INT8_CODES),
+    ("large-v3 int8_float16", "beam"): (1e-2, 3.7e-3, INT8_CODES),
     ("large-v3 int8_float16", "lang"): (6e-2, 3.8e-2, INT8_CODES),
-    ("large-v3 int8_float16", "align"): (5e-2, 2.0e-2, INT8_CODES),
+    ("large-v3 int8_float16", "align"): (5e-2, 2.5e-2, INT8_CODES),
 }
+# measured on the box with everything else at NORTH_STAR (round 3, profiles/r03_pytest_gpu.log): large-v3 float16 beam
+# scores 2.0e-4 / 2.6e-4 over 48 steps, no-speech 5e-10; distil-large-v3 per token 3.2e-4, beam 5e-5, language 5.7e-4,
+# align 5.0e-4; int8 no-speech 7e-9; merged runs (24 steps) 1.2e-4 / 2.5e-4, int8 2.1e-3
 
 
 def tolerance(cfg_name, compute_type, what):

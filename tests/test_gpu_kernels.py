@@ -41,11 +41,23 @@ def _gemm(model, A, W, bias=None, res=None, act=0):
     return out
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["staggered-groups", "pipelined-stream", "pipelined-dma-mid"])
+def gemm_pipe(request):
+    """both K-loop forms of the many-rows GEMM (csrc/gemm.hip, PIPE = 0 / 1) go through every parity case"""
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    old = lib.fw_test_set_gemm_pipe(request.param)
+    yield request.param
+    lib.fw_test_set_gemm_pipe(old)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (300, 256, 128), (1500, 512, 1280),
                                    (3000, 128, 384), (77, 128, 256),
                                    # many M tiles, ragged last tile
-                                   (1024, 256, 64), (1500, 768, 192), (1031, 256, 128)])
-def test_gemm_plain(model, M, N, K):
+                                   (1024, 256, 64), (1500, 768, 192), (1031, 256, 128),
+                                   # long K (80 K tiles: the steady state of the DMA ring), one to three K tiles
+                                   (700, 512, 5120), (260, 256, 192)])
+def test_gemm_plain(model, gemm_pipe, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
     # asymmetric W so a transposed C write cannot pass
@@ -58,7 +70,7 @@ def test_gemm_plain(model, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 256, 192), (1100, 256, 192)])   # one and many M tiles
-def test_gemm_epilogues(model, M, N, K):
+def test_gemm_epilogues(model, gemm_pipe, M, N, K):
     rng = np.random.default_rng(5)
     A = _h(rng.standard_normal((M, K)).astype(np.float32) * 0.5)
     W = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.2)
@@ -73,7 +85,7 @@ def test_gemm_epilogues(model, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1500, 256, 128), (1027, 512, 64)])
-def test_gemm_transposed_output(model, M, N, K):
+def test_gemm_transposed_output(model, gemm_pipe, M, N, K):
     rng = np.random.default_rng(6)
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
     W = _h(rng.standard_normal((N, K)).astype(np.float32))
@@ -199,12 +211,16 @@ def test_dec_linear_layernorm_folded_gelu(model, R, N, K):
         assert np.array_equal(out, out_frag)
 
 
-@pytest.mark.parametrize("R", [80, 333, 1680])
-def test_dec_linear_tile_bit_identical(model, R):
-    """the GEMM-shaped decoder linear for merged runs (dec_gemm_tile_kernel: operands staged once per 128 x 64
-    workgroup tile in LDS) must return EXACTLY the bits of the product's skinny kernel at every large-v3 step shape —
-    it keeps that kernel's K slices, MFMA chains and addition order — so that a merged decode run stays
-    bit-identical to a solo run whichever kernel serves it"""
+BIG_CFGS = (0, 1, 2, 3, 4, 5)     # workgroup shapes of dec_gemm_big_kernel (dec_kernels.hip: launch_dec_gemm_big)
+
+
+@pytest.mark.parametrize("R", [80, 333, 1521, 1680])
+def test_dec_linear_big_bit_identical(model, R):
+    """the GEMM-shaped decoder linear of merged runs (dec_gemm_big_kernel: 64 x 64 outputs per wave, fragments staged
+    once per workgroup tile in LDS) must return EXACTLY the bits of the skinny kernel of solo runs at every large-v3
+    step shape — it keeps that kernel's K slices, MFMA chains and addition order, and both end in the same pinned
+    epilogue — so that a merged decode run stays bit-identical to a solo run whichever kernel serves it.  Every
+    workgroup shape is checked (ragged row and column tile tails included: 333, 1521 rows)"""
     rng = np.random.default_rng(900 + R)
     for N, K, ln, act, use_res in ((1280, 1280, False, 0, True), (3840, 1280, True, 0, False),
                                    (5120, 1280, True, 1, False), (1280, 5120, False, 0, True)):
@@ -215,12 +231,38 @@ def test_dec_linear_tile_bit_identical(model, R):
         lnp = (_h(1 + 0.1 * rng.standard_normal(K).astype(np.float32)),
                _h(0.05 * rng.standard_normal(K).astype(np.float32))) if ln else None
         a, a_frag = _dec_linear(model, x, W, bias=b, ln=lnp, res=r, act=act, int8=5)    # the skinny kernel
-        for variant in (0, 2, 3, 4):  # what a decode step launches at this row count; tile kernel: 2, 3, 4 stages
+        # and against fp64, so that "identical" cannot mean "identically wrong"
+        base = (_ln_ref(x.astype(np.float64), *lnp) if ln else x.astype(np.float64)) @ W.T.astype(np.float64) + b
+        ref = (_gelu(base) if act else base) + (r if use_res else 0.0)
+        err = np.abs(a - ref).max() / max(1.0, np.abs(ref).max())
+        assert err < 4e-3, (N, K, err)
+        for variant in (0,) + tuple(10 + c for c in BIG_CFGS):  # 0: what a decode step launches at this row count
             t, t_frag = _dec_linear(model, x, W, bias=b, ln=lnp, res=r, act=act, int8=variant)
             same = np.array_equal(a, t)
-            print(f"tile[{variant}] vs skinny {R}x{N}x{K} ln={ln} act={act}: identical={same}, "
+            print(f"big[{variant}] vs skinny {R}x{N}x{K} ln={ln} act={act}: identical={same}, "
                   f"max diff {np.abs(a - t).max():.2e}")
-            assert same and np.array_equal(a_frag, t_frag)
+            assert same and np.array_equal(a_frag, t_frag), (variant, N, K)
+
+
+def test_dec_linear_big_odd_shapes(model):
+    """column counts that do not fill a workgroup tile, a single row tile, tiny.en's d = 384 (K = 384: 3 k-steps per slice)"""
+    rng = np.random.default_rng(5)
+    for R, N, K in ((17, 384, 384), (130, 1536, 384), (600, 384, 1536), (257, 1280, 1280)):
+        x = _h(rng.standard_normal((R, K)).astype(np.float32))
+        W = _h((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        b = _h(0.1 * rng.standard_normal(N).astype(np.float32))
+        a, a_frag = _dec_linear(model, x, W, bias=b, int8=5)
+        ref = x @ W.T + b
+        assert np.abs(a - ref).max() / max(1.0, np.abs(ref).max()) < 2e-3
+        n_ok = 0
+        for c in BIG_CFGS:
+            try:
+                t, t_frag = _dec_linear(model, x, W, bias=b, int8=10 + c)
+            except RuntimeError:        # a k-steps-per-stage that does not divide this K's slices: the launcher refuses
+                continue
+            n_ok += 1
+            assert np.array_equal(a, t) and np.array_equal(a_frag, t_frag), (c, R, N, K)
+        assert n_ok >= 2, (R, N, K)
 
 
 @pytest.mark.parametrize("R", [1, 5, 16, 48, 64, 80, 83, 640])
