@@ -63,18 +63,16 @@ static __device__ __forceinline__ void dec_ln_stats(float sa, float sb, int K, f
 template <bool LNF>
 static __device__ __forceinline__ half4_t dec_epilogue4(const floatx4 v, float mu, float rstd,
                                                         const float* __restrict__ s1, const float* __restrict__ cf,
-                                                        const half_t* __restrict__ bias, const half_t* __restrict__ res,
-                                                        int ldr, int row, int n, int act) {
+                                                        const half_t* __restrict__ bias, bool has_res, half4_t r4, int n, int act) {
 #pragma clang fp contract(off)
   floatx4 a4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
-  half4_t b4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}, r4 = b4;
+  half4_t b4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
   if (LNF) {
     a4 = *reinterpret_cast<const floatx4*>(s1 + n);
     c4 = *reinterpret_cast<const floatx4*>(cf + n);
   } else if (bias) {
     b4 = *reinterpret_cast<const half4_t*>(bias + n);
   }
-  if (res) r4 = *reinterpret_cast<const half4_t*>(res + (size_t)row * ldr + n);
   half4_t o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -89,7 +87,7 @@ static __device__ __forceinline__ half4_t dec_epilogue4(const floatx4 v, float m
       const float er = erff(tv * 0.70710678118654752440f);
       tv = (0.5f * tv) * (1.0f + er);
     }
-    if (res) tv = tv + (float)r4[e];
+    if (has_res) tv = tv + (float)r4[e];
     o[e] = (half_t)tv;
   }
   return o;
@@ -125,8 +123,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
   const int n_rt = (R + 15) >> 4;
+  const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
   const int KS = K >> 5;
   const int per = (KS + WAVES - 1) / WAVES;
   const int ks0 = wave * per;
@@ -144,8 +142,11 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
     const half8_t* wp[NT];
     const half8_t* xp[RT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
-      wp[b] = reinterpret_cast<const half8_t*>(Wf) + ((size_t)(ct0 + b) * KS + ks0) * 64 + lane;
+    for (int b = 0; b < NT; ++b) {
+      int ct = ct0 + b;
+      if (ct > (N >> 4) - 1) ct = (N >> 4) - 1;   // a missing column tile re-reads the last one; never stored
+      wp[b] = reinterpret_cast<const half8_t*>(Wf) + ((size_t)ct * KS + ks0) * 64 + lane;
+    }
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
       int rt = rt0 + a;
@@ -219,8 +220,11 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
         dec_ln_stats(sa, sb, K, mu, rstd);
       }
       const int n = (ct0 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
+      if (n >= N) continue;
       const floatx4 v4 = {v[0], v[1], v[2], v[3]};
-      const half4_t o = dec_epilogue4<LNF>(v4, mu, rstd, s1, cf, bias, res, ldr, row, n, act);
+      half4_t r4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      if (res) r4 = *reinterpret_cast<const half4_t*>(res + (size_t)row * ldr + n);
+      const half4_t o = dec_epilogue4<LNF>(v4, mu, rstd, s1, cf, bias, res != nullptr, r4, n, act);
       if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
       if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
     }
@@ -228,22 +232,30 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// GEMM-shaped form of the decoder linear for MERGED decode runs (hundreds to 2 000 rows).  The skinny kernel above
-// moves every x / W fragment from L2 once per 32 x 32 outputs and runs at ~360 TFLOP/s at 1 680 rows; at those row
-// counts the linears are ordinary MFMA-bound GEMMs.  Here:
-//   * one wave owns 64 rows x 64 columns (4 x 4 tiles: every fragment read from LDS feeds 4 MFMAs); a workgroup is
-//     WM x WN waves = (64 WM) rows x (64 WN) columns;
-//   * operands are FRAGMENT-MAJOR in HBM, so a k-step of the workgroup tile is 4 (WM + WN) contiguous 1 KB pieces: one
+// GEMM-shaped, LDS-staged form of the decoder linear for MERGED decode runs (a thousand rows and more).  The
+// register-streaming kernel above re-reads every operand fragment once per workgroup tile and runs into the ~33 B/clk a
+// CU's vector-memory path delivers; here a workgroup of WM x WN waves stages the fragments of a (64 WM) x (16 FB WN)
+// tile ONCE in LDS for all its waves:
+//   * one wave owns 64 rows x 16 FB columns (4 x FB tiles of 16 x 16: every fragment read from LDS feeds 4 or FB MFMAs);
+//   * operands are FRAGMENT-MAJOR in HBM, so a k-step of the workgroup tile is 4 WM + FB WN contiguous 1 KB pieces: one
 //     global_load_lds per piece (a wave instruction moves exactly one MFMA fragment), the LDS image is the fragment
 //     itself and every ds_read_b128 is lane-linear: no swizzle, no bank conflicts;
 //   * ring of NST stages of KC k-steps, ONE barrier per stage: wait (counted vmcnt, NST - 2 stages stay in flight)
-//     -> barrier -> refill the stage read last -> 16 KC MFMAs per wave;
+//     -> barrier -> refill the stage read last -> 4 FB KC MFMAs per wave;
+//   * epilogue through the idle ring: the accumulator layout gives a lane 4 consecutive columns of ONE row (16 stores
+//     of 8 bytes into 16 different lines per instruction, twice: row-major and fragment-major — store-issue bound,
+//     measured ~5 us per launch).  Instead the residual tile is fetched in whole 128-byte row segments into the wave's
+//     LDS patch, every lane computes its four values there (the pinned dec_epilogue4 arithmetic, unchanged), and the
+//     finished tile leaves in 16-byte pieces: row segments for the row-major copy, whole 1 KB fragments for the
+//     fragment-major copy the next linear reads;
 //   * BIT-IDENTICAL to dec_gemm_frag_kernel<S waves>: that kernel cuts K into S slices of consecutive k-steps, runs one
 //     MFMA chain per slice from a zero accumulator and adds the slice partials in slice order starting from 0.0f
 //     (likewise the LayerNorm statistics).  The same chains and the same additions are made here by one wave — at a
-//     slice boundary  total += acc; acc = 0  — and both kernels share the pinned epilogue (dec_epilogue4).  So a
-//     merged run returns exactly what each caller's solo run returns (tests/test_gpu_kernels.py::
-//     test_dec_linear_big_bit_identical, tests/test_gpu_full_size.py::test_merged_run_*).
+//     slice boundary  total += acc; acc = 0  — and both kernels share the pinned epilogue arithmetic.  So a merged run
+//     returns exactly what each caller's solo run returns (tests/test_gpu_kernels.py::test_dec_linear_big_bit_identical).
+// What was measured on the way (profiles/r03_dec_linear_bench.txt, NOTES.md): staging alone costs ~670 cycles per 16 KB
+// k-step with four waves issuing (25 B/clk per CU: the LDS-DMA issue, not its latency — a deeper ring, or touching the
+// lines of later stages into L2 ahead of time, made it slower), the MFMA side alone ~550.
 // ------------------------------------------------------------------------------------
 template <int N_>
 static __device__ __forceinline__ void wait_vmcnt() {
@@ -258,28 +270,28 @@ static __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("" ::: "memory");         \
   } while (0)
 
-template <bool LNF, int S, int WM, int WN, int KC, int NST, int PF>
+template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
 __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
     half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act, int nNt) {
   constexpr int NW = WM * WN;
-  constexpr int PX = 4 * WM, PW = 4 * WN, PCS = PX + PW;   // fragments (1 KB pieces) of one k-step: x row tiles, W column tiles
+  constexpr int PX = 4 * WM, PW = FB * WN, PCS = PX + PW;   // fragments (1 KB pieces) of one k-step: x row tiles, W column tiles
   static_assert((PCS * KC) % NW == 0, "pieces of a stage must divide over the waves");
+  static_assert(FB == 2 || FB == 4, "column tiles per wave");
   constexpr int PPW = PCS * KC / NW;                       // pieces a wave issues per stage
   constexpr int STAGE_BYTES = PCS * KC * 1024;
-  static_assert(NST >= 2 && NST <= 9, "ring depth");
-  constexpr int GRP = PPW + (PF > 0 ? 1 : 0);             // memory instructions a wave issues per stage
-  static_assert(8 * PPW <= 64, "one touch instruction covers the wave's pieces of a stage");
-  // NST stages + (PF > 0) 256 B per wave that the L2 touches land in (the only LDS object of the kernel)
-  extern __shared__ __attribute__((aligned(16))) char dgb_smem[];
+  static_assert(NST >= 3 && NST <= 6, "ring depth");
+  // bytes per staged output row: the patch row + 16 (conflict-free 8-byte column writes, 16-byte aligned rows)
+  constexpr int DGB_EP_STRIDE = FB * 32 + 16;
+  static_assert(NST * STAGE_BYTES >= NW * 64 * DGB_EP_STRIDE, "the epilogue stages one 64-row patch per wave through the ring");
+  extern __shared__ __attribute__((aligned(16))) char dgb_smem[];   // NST stages (the only LDS object of the kernel)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
-  // consecutive tiles run on one XCD (xcd_remap) and share the W column tile — the operand that is cold in HBM (the
-  // weights of a step are 1.5 GB: never cached from one use to the next) is fetched once per XCD, its row-panel
-  // siblings hit that XCD's L2
+  // consecutive tiles run on one XCD (xcd_remap) and share the W column tile: the cold operand (a step's weights are
+  // 1.5 GB, never cached from one use to the next) is fetched once per XCD
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int nMt = gridDim.x / nNt;
   const int nt = bid / nMt, mt = bid - nt * nMt;
@@ -287,12 +299,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
   const int n_rt = (R + 15) >> 4;
   const int KS = K >> 5;
   const int per = KS / S;                 // k-steps per slice (the launcher guarantees KS % S == 0, per % KC == 0)
-  const int nch = KS / KC;                // stages' worth of K
+  const int nch = KS / KC;                // stages' worth of K (the launcher guarantees nch >= NST)
   const int ch_per_slice = per / KC;
 
   // staging: piece p of a stage = (tile t = p / KC, k-step p % KC); tiles 0 .. PX-1 are x row tiles, PX .. PCS-1 W
-  // column tiles; wave w issues pieces w * PPW .. + PPW - 1
-  const char* src[PPW];
+  // column tiles; wave w issues pieces w * PPW .. + PPW - 1.  32-bit offsets from the wave-uniform operand bases (the
+  // DMA instruction takes SGPR base + VGPR offset); which base a piece uses is a compile-time fact per (wave, q) only
+  // when PPW divides the x / W boundary, so the base is picked with a wave-uniform select.
+  unsigned soff[PPW];
+  const char* sbase[PPW];
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int p = wave * PPW + q;
@@ -300,93 +315,42 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     if (t < PX) {
       int rt = rt0 + t;
       if (rt > n_rt - 1) rt = n_rt - 1;   // a missing row tile re-reads the last one; its result is dropped
-      src[q] = reinterpret_cast<const char*>(xf) + (((size_t)rt * KS + ks) * 64 + lane) * 16;
+      sbase[q] = reinterpret_cast<const char*>(xf);
+      soff[q] = (unsigned)((((size_t)rt * KS + ks) * 64 + lane) * 16);
     } else {
       int ct = ct0 + t - PX;
       if (ct > (N >> 4) - 1) ct = (N >> 4) - 1;   // a missing column tile re-reads the last one; never stored
-      src[q] = reinterpret_cast<const char*>(Wf) + (((size_t)ct * KS + ks) * 64 + lane) * 16;
+      sbase[q] = reinterpret_cast<const char*>(Wf);
+      soff[q] = (unsigned)((((size_t)ct * KS + ks) * 64 + lane) * 16);
     }
   }
-  // L2 touch (PF > 0): the ring holds NST - 1 stages = a few tens of KB in flight per CU, which hides an L2 hit but
-  // not an HBM (W) or Infinity-Cache (x, written by the previous kernel on other XCDs) miss.  So every stage's DMA
-  // group carries one more instruction that pulls the lines of the stage PF further on into this XCD's L2: a 4-byte
-  // LDS-DMA per lane, lane l = (piece l / 8 of this wave, 128-byte line l % 8), landing in a 256-byte dump area.
-  // Same instruction kind as the pieces: the counted vmcnt protocol just counts GRP = PPW + 1 per stage.
-  const char* tsrc = nullptr;
-  if (PF > 0) {
-    const int tl = lane % (8 * PPW);
-    const int p = wave * PPW + (tl >> 3);
-    const int t = p / KC, ks = p % KC;
-    if (t < PX) {
-      int rt = rt0 + t;
-      if (rt > n_rt - 1) rt = n_rt - 1;
-      tsrc = reinterpret_cast<const char*>(xf) + ((size_t)rt * KS + ks) * 1024 + (tl & 7) * 128;
-    } else {
-      int ct = ct0 + t - PX;
-      if (ct > (N >> 4) - 1) ct = (N >> 4) - 1;
-      tsrc = reinterpret_cast<const char*>(Wf) + ((size_t)ct * KS + ks) * 1024 + (tl & 7) * 128;
-    }
-  }
-  char* const dump = dgb_smem + NST * STAGE_BYTES + wave * 256;
-  auto touch = [&](int c) {               // lines of K stage c (clamped: a touch past the end repeats the last stage)
-    if (PF > 0) {
-      const int cc = c < nch ? c : nch - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + (size_t)cc * KC * 1024),
-                                       (__attribute__((address_space(3))) void*)dump, 4, 0, 0);
-    }
-  };
-  auto issue = [&](int c, int slot) {   // K stage c -> ring slot (+ the touch of stage c + PF)
+  auto issue = [&](int c, int slot) {   // K stage c -> ring slot
     char* dst = dgb_smem + slot * STAGE_BYTES + wave * PPW * 1024;
-    const size_t koff = (size_t)c * KC * 1024;   // KC k-steps further along every tile's fragment run
+    const unsigned koff = (unsigned)c * (KC * 1024);   // KC k-steps further along every tile's fragment run
 #pragma unroll
     for (int q = 0; q < PPW; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase[q] + (size_t)(soff[q] + koff)),
                                        (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-    touch(c + PF);
   };
 
-  floatx4 acc[4][4], tot[4][4];
+  floatx4 acc[4][FB], tot[4][FB];
   float rs[4], rq[4], sa[4], sb[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     rs[a] = 0.f; rq[a] = 0.f; sa[a] = 0.f; sb[a] = 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
+    for (int b = 0; b < FB; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
   }
 
-  if (PF > 0) {
-    // stages 0 .. PF - 1 are touched up front (older than every piece, they retire first: the counts below hold)
-    for (int c0 = 0; c0 < PF; ++c0) touch(c0);
-  }
-#pragma unroll
-  for (int c0 = 0; c0 < NST - 1; ++c0)
-    if (c0 < nch) issue(c0, c0);
-  int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
-  int to_slice = ch_per_slice;
-  for (int c = 0; c < nch; ++c) {
-    // stages c .. min(c + NST - 2, nch - 1) are in flight: wait until only the younger ones are
-    const int younger = (nch - 1 - c) < (NST - 2) ? (nch - 1 - c) : (NST - 2);
-    switch (younger) {
-      case 0: wait_vmcnt<0>(); break;
-      case 1: wait_vmcnt<1 * GRP>(); break;
-      case 2: wait_vmcnt<2 * GRP>(); break;
-      case 3: wait_vmcnt<3 * GRP>(); break;
-      case 4: wait_vmcnt<4 * GRP>(); break;
-      case 5: wait_vmcnt<5 * GRP>(); break;
-      case 6: wait_vmcnt<6 * GRP>(); break;
-      default: wait_vmcnt<7 * GRP>(); break;
-    }
-    DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
-    if (c + NST - 1 < nch) issue(c + NST - 1, fill);   // ... whose slot is the one refilled now
+  auto compute = [&](int slot) {          // the MFMAs of one stage
     const char* st = dgb_smem + slot * STAGE_BYTES;
-    // every fragment of the stage is requested up front (16 KC bytes per lane in flight), the MFMAs then wait with
-    // counted lgkmcnt for exactly the operands they need: the LDS latency is paid once per stage, under the MFMAs
-    half8_t xv[KC][4], wv[KC][4];
+    // every fragment of the stage is requested up front, the MFMAs then follow the counted LDS waits
+    half8_t xv[KC][4], wv[KC][FB];
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        wv[ks][b] = *reinterpret_cast<const half8_t*>(st + (((PX + wn * 4 + b) * KC + ks) * 64 + lane) * 16);
+      for (int b = 0; b < FB; ++b)
+        wv[ks][b] = *reinterpret_cast<const half8_t*>(st + (((PX + wn * FB + b) * KC + ks) * 64 + lane) * 16);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
         xv[ks][a] = *reinterpret_cast<const half8_t*>(st + (((wm * 4 + a) * KC + ks) * 64 + lane) * 16);
@@ -397,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < FB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][b], xv[ks][a], acc[a][b], 0, 0, 0);
         if (LNF) {
           const half2_t one2 = {(half_t)1.f, (half_t)1.f};
@@ -410,43 +374,104 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
         }
       }
     }
-    if (--to_slice == 0) {   // slice boundary: the skinny kernel's fixed-order reduction, one term at a time
-      to_slice = ch_per_slice;
+  };
+  auto slice_end = [&]() {                // the skinny kernel's fixed-order reduction, one term at a time
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        if (LNF) {
-          float pa = rs[a], pb = rq[a];
-          pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
-          pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
-          sa[a] += pa; sb[a] += pb;
-          rs[a] = 0.f; rq[a] = 0.f;
-        }
+    for (int a = 0; a < 4; ++a) {
+      if (LNF) {
+        float pa = rs[a], pb = rq[a];
+        pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
+        pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
+        sa[a] += pa; sb[a] += pb;
+        rs[a] = 0.f; rq[a] = 0.f;
+      }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < FB; ++b) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tot[a][b][e] += acc[a][b][e];
-          acc[a][b] = floatx4{0, 0, 0, 0};
-        }
+        for (int e = 0; e < 4; ++e) tot[a][b][e] += acc[a][b][e];
+        acc[a][b] = floatx4{0, 0, 0, 0};
       }
     }
+  };
+
+#pragma unroll
+  for (int c0 = 0; c0 < NST - 1; ++c0) issue(c0, c0);
+  int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
+  int to_slice = ch_per_slice;
+  const int n_steady = nch - (NST - 1);
+  // steady state: stages c .. c + NST - 2 are in flight; wait until only the NST - 2 younger ones are
+  for (int c = 0; c < n_steady; ++c) {
+    wait_vmcnt<(NST - 2) * PPW>();
+    DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
+    issue(c + NST - 1, fill);             // ... whose slot is the one refilled now
+    compute(slot);
+    if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
     fill = slot;
     slot = (slot + 1 == NST) ? 0 : slot + 1;
   }
+  // tail: nothing left to issue; the queue is drained once
+  wait_vmcnt<0>();
+#pragma unroll 1
+  for (int c = n_steady; c < nch; ++c) {
+    DGB_BARRIER();
+    compute(slot);
+    if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+    slot = (slot + 1 == NST) ? 0 : slot + 1;
+  }
+  DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
 
-  // epilogue: the skinny kernel's (dec_epilogue4), straight from registers
+  // ---------------------------------- epilogue ----------------------------------
+  char* ep = dgb_smem + wave * (64 * DGB_EP_STRIDE);       // this wave's 64-row x (16 FB)-column patch, fp16
+  const int row0 = (rt0 + wm * 4) * 16;                    // first row / column of the wave's patch
+  const int col0 = (ct0 + wn * FB) * 16;
+  constexpr int CPR = FB * 2;                              // 16-byte chunks per patch row
+  constexpr int RPI = 64 / CPR;                            // patch rows one wave instruction covers
+  const int cr = lane / CPR, cc = lane % CPR;              // row-segment pass: this lane's row within the group, chunk
+  if (res) {   // residual patch -> LDS in whole row segments (a wave's LDS operations execute in order)
+#pragma unroll
+    for (int j = 0; j < 64 / RPI; ++j) {
+      const int r = j * RPI + cr;
+      const int row = row0 + r, n = col0 + cc * 8;
+      intx4 v = {0, 0, 0, 0};
+      if (row < R && n < N) v = *reinterpret_cast<const intx4*>(res + (size_t)row * ldr + n);
+      *reinterpret_cast<intx4*>(ep + r * DGB_EP_STRIDE + cc * 16) = v;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const int row = (rt0 + wm * 4 + a) * 16 + i;
-    if (row >= R) continue;
     float mu = 0.f, rstd = 1.f;
     if (LNF) dec_ln_stats(sa[a], sb[a], K, mu, rstd);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int n = (ct0 + wn * 4 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
-      if (n >= N) continue;
-      const half4_t o = dec_epilogue4<LNF>(tot[a][b], mu, rstd, s1, cf, bias, res, ldr, row, n, act);
-      if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
-      if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
+    for (int b = 0; b < FB; ++b) {
+      int n = col0 + b * 16 + 4 * g;                       // this lane: D[n + e][row], e = 0..3
+      if (n > N - 4) n = N - 4;                            // clamped columns are never stored
+      char* cell = ep + (a * 16 + i) * DGB_EP_STRIDE + (b * 16 + 4 * g) * 2;
+      half4_t r4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      if (res) r4 = *reinterpret_cast<const half4_t*>(cell);
+      const half4_t o = dec_epilogue4<LNF>(tot[a][b], mu, rstd, s1, cf, bias, res != nullptr, r4, n, act);
+      *reinterpret_cast<half4_t*>(cell) = o;
+    }
+  }
+  if (out) {   // row-major copy: whole row segments, 16 bytes per lane
+#pragma unroll
+    for (int j = 0; j < 64 / RPI; ++j) {
+      const int r = j * RPI + cr;
+      const int row = row0 + r, n = col0 + cc * 8;
+      const intx4 v = *reinterpret_cast<const intx4*>(ep + r * DGB_EP_STRIDE + cc * 16);
+      if (row < R && n < N) *reinterpret_cast<intx4*>(out + (size_t)row * ldo + n) = v;
+    }
+  }
+  if (out_frag) {   // fragment-major copy: one whole 1 KB fragment (16 rows x 32 columns) per wave instruction
+    const int KSo = N >> 5;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int kb = 0; kb < FB / 2; ++kb) {
+        const int row = row0 + a * 16 + i, n = col0 + kb * 32 + g * 8;   // lane (i, g): row i, column octet g
+        const intx4 v = *reinterpret_cast<const intx4*>(ep + (a * 16 + i) * DGB_EP_STRIDE + (kb * 32 + g * 8) * 2);
+        if (row < R && n < N)
+          *reinterpret_cast<intx4*>(out_frag + ((size_t)((row >> 4) * KSo + (n >> 5)) * 64 + lane) * 8) = v;
+      }
     }
   }
 }
@@ -1389,58 +1414,59 @@ __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __re
 
 namespace fwd {
 
-// row count from which a decode run takes the GEMM-shaped decoder linear, and its workgroup shape
+// row count from which the decoder linears of a decode run take the LDS-staged GEMM-shaped kernel
 // (profiles/r03_dec_linear_bench.txt)
-#define DEC_BIG_MIN_ROWS 512
-#define DEC_BIG_CFG 0
+#define DEC_BIG_MIN_ROWS 1024
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d, const int* d_step, int pos_fixed, int P) {
   dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, xfrag, d, d_step, pos_fixed, P);
 }
 
-template <bool LNF, int RT, int NT>
+template <bool LNF, int RT, int NT, int CH = 0>
 static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N,
                     int K, int act) {
-  const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
+  const dim3 grid((N / 16 + NT - 1) / NT, ((R + 15) / 16 + RT - 1) / RT);
   if (waves == 8)
-    dec_gemm_frag_kernel<8, LNF, RT, NT><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N,
-                                                               K, act);
+    dec_gemm_frag_kernel<8, LNF, RT, NT, CH><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R,
+                                                                   N, K, act);
   else
-    dec_gemm_frag_kernel<4, LNF, RT, NT><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N,
-                                                               K, act);
+    dec_gemm_frag_kernel<4, LNF, RT, NT, CH><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R,
+                                                                   N, K, act);
 }
 
 // GEMM-shaped kernel of merged runs (dec_gemm_big_kernel), workgroup shape `cfg`; -1 when the shape does not fit.
-//   cfg 0: 2 x 2 waves (128 x 128), 1 k-step per stage, 4 stages (64 KB: two workgroups per CU), L2 touch 10 stages ahead
-//   cfg 1: 4 x 2 waves (256 rows x 128 columns), 2 k-steps per stage, 3 stages (144 KB), touch 5 stages ahead
-//   cfg 2: 2 x 2 waves, 1 k-step per stage, 4 stages, no touch
-//   cfg 3: 2 x 2 waves, 1 k-step per stage, 9 stages (144 KB: one workgroup per CU, 128 KB in flight), no touch
-//   cfg 4: 2 x 2 waves, 1 k-step per stage, 4 stages, touch 20 stages ahead
-//   cfg 5: 2 x 4 waves (128 rows x 256 columns), 2 k-steps per stage, 3 stages, touch 5 stages ahead
-template <bool LNF, int S, int WM, int WN, int KC, int NST, int PF>
+//   cfg 0: 4 x 2 waves, 256 rows x 128 columns, 2 k-steps per stage, 3 stages (144 KB)  — the wide linears (qkv, ffn1)
+//   cfg 1: 2 x 2 waves, 128 rows x 64 columns (2 column tiles per wave), 1 k-step per stage, 5 stages (60 KB, two
+//          workgroups per CU) — the linears with 1280 columns (out / cross-q / cross-out, ffn2), which a wider tile
+//          cannot spread over the chip
+//   cfg 2: 2 x 2 waves, 128 x 128, 1 k-step per stage, 4 stages (64 KB)
+// (measured next to 256 x 64, 128 x 256, 8 waves on 128 x 128, deeper rings, two k-steps per barrier, LDS reads
+//  software-pipelined under the MFMAs, L2 touch-ahead: profiles/r03_dec_linear_bench.txt — none better)
+template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
 static void big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
-  constexpr int lds = 4 * (WM + WN) * KC * 1024 * NST + (PF > 0 ? WM * WN * 256 : 0);
+  constexpr int lds = (4 * WM + FB * WN) * KC * 1024 * NST;
   static bool attr_set = false;   // (per instantiation)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, KC, NST, PF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  const int nMt = ((R + 15) / 16 + 4 * WM - 1) / (4 * WM), nNt = (N / 16 + 4 * WN - 1) / (4 * WN);
-  dec_gemm_big_kernel<LNF, S, WM, WN, KC, NST, PF><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out,
-                                                                                      ldo, out_frag, R, N, K, act, nNt);
+  const int nMt = ((R + 15) / 16 + 4 * WM - 1) / (4 * WM), nNt = (N / 16 + FB * WN - 1) / (FB * WN);
+  dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
+                                                                                      out_frag, R, N, K, act, nNt);
 }
-template <int WM, int WN, int KC, int NST, int PF>
+template <int WM, int WN, int FB, int KC, int NST>
 static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
-  if (K % 32 != 0 || N % 16 != 0 || R < 1) return -1;
+  if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
   const int S = K >= 2560 ? 8 : 4;   // the slice count of launch_dec_gemm_skinny's instantiation for this K
   const int KS = K / 32;
-  if (KS % S != 0 || (KS / S) % KC != 0) return -1;
-#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, KC, NST, PF>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
+  if (KS % S != 0 || (KS / S) % KC != 0 || KS / KC < NST) return -1;
+  if ((ldo % 8) || (res && (ldr % 8))) return -1;   // 16-byte row segments
+#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, FB, KC, NST>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
   if (s1) { if (S == 8) DGB(true, 8); else DGB(true, 4); }
   else { if (S == 8) DGB(false, 8); else DGB(false, 4); }
 #undef DGB
@@ -1450,12 +1476,9 @@ int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t*
                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                         int N, int K, int act) {
   switch (cfg) {
-    case 0: return big_cfg<2, 2, 1, 4, 10>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 1: return big_cfg<4, 2, 2, 3, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 2: return big_cfg<2, 2, 1, 4, 0>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 3: return big_cfg<2, 2, 1, 9, 0>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 4: return big_cfg<2, 2, 1, 4, 20>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 5: return big_cfg<2, 4, 2, 3, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 0: return big_cfg<4, 2, 4, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 1: return big_cfg<2, 2, 2, 1, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 2: return big_cfg<2, 2, 4, 1, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     default: return -1;
   }
 }
@@ -1487,7 +1510,9 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 7: frag_variant<8, 2, 4, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 8: frag_variant<8, 8, 2, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 9: frag_variant<4, 4, 4, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
-    case 10: case 11: case 12: case 13: case 14: case 15:
+    case 21: frag_variant<4, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 22: frag_variant<8, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 10: case 11: case 12:
       return launch_dec_gemm_big(st, variant - 10, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr,
                                  nullptr, 0, out, N, nullptr, R, N, K, 0);
     default: return -1;
@@ -1502,8 +1527,11 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                          int N, int K, int act) {
-  // merged runs: the GEMM-shaped kernel (bit-identical by construction and by test); solo runs: the skinny kernel
-  if (R >= DEC_BIG_MIN_ROWS && launch_dec_gemm_big(st, DEC_BIG_CFG, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
+  // Merged runs of >= DEC_BIG_MIN_ROWS rows: the LDS-staged GEMM-shaped kernel, 256 x 128 tiles for the wide linears and
+  // 128 x 64 for those with 1280 columns (measured per layer at 1 520 rows: 216 -> 157 us; the register-streaming kernel
+  // with 4 x 4 tiles reaches 174: profiles/r03_dec_linear_bench.txt).  Same K slices, same reduction order, same pinned
+  // epilogue as the register-streaming kernel: the same bits.
+  if (R >= DEC_BIG_MIN_ROWS && launch_dec_gemm_big(st, N >= 2560 ? 0 : 1, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
     return 0;
   return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
 }

@@ -35,6 +35,9 @@ namespace fw {
 using fwd::FIN_CAP;
 using fwd::GenDev;
 
+// rows of a merged decode run above which a second, nearly empty round of workgroups starts (dec_kernels.hip)
+#define DEC_RUN_MAX_ROWS 1600
+
 struct GraphSlot {
   hipGraphExec_t exec = nullptr;
   GenDev key;
@@ -734,7 +737,11 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     GenRequest* first = grp.queue.front();
     int chunks = 0;
     // chunks the self-attention cache holds at this call's context (mergeable calls share max_length and P)
-    const int run_cap = std::min<int64_t>(cap, self_chunk_capacity(dm, *first));
+    // ... and the rows above which the 4 x 4-tile decoder linears no longer fit the chip in one round of workgroups
+    // (d x d: 20 column groups x 25 row groups of 64 rows = 500 of 512 workgroup slots)
+    int64_t run_cap = std::min<int64_t>(cap, self_chunk_capacity(dm, *first));
+    if (!first->sampling)
+      run_cap = std::min<int64_t>(run_cap, std::max<int64_t>(dm->max_batch, DEC_RUN_MAX_ROWS / std::max(1, first->o->beam_size)));
     for (auto it = grp.queue.begin(); it != grp.queue.end();) {
       GenRequest* r = *it;
       if (r == first || (mergeable(*first, *r) && chunks + r->B <= run_cap)) {

@@ -1766,12 +1766,6 @@ int32_t fw_bench_dec_linear(fw_model* fm, int32_t R, int32_t N, int32_t K, int32
 
 // measurement hook (profiles/gemm_bench.py): the encoder GEMM on device-resident pseudo-random operands,
 // `iters` launches between two events.  lda = K + a_pad, ldw = K + w_pad elements (stride experiments).
-int32_t fw_test_set_gemm_pipe(int32_t pipe) {
-  const int old = fwk::get_gemm_pipe();
-  fwk::set_gemm_pipe(pipe);
-  return old;
-}
-
 int32_t fw_bench_gemm(fw_model* fm, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
                       int32_t trans, int32_t iters, float* ms_out) {
   FW_CHECK_ARG(fm && ms_out && M > 0 && N > 0 && K > 0 && batch > 0 && iters > 0, "bad argument");

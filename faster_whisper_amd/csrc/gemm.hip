@@ -43,8 +43,8 @@
 //    the A panel and the whole W in that XCD's L2.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
-#define GB_PIPE_DEFAULT 0
 #define GB_M 256
 #define GB_N 256
 #define GB_UNIT_BYTES (128 * 128)          // one staging unit: 128 rows x 128 B
@@ -71,7 +71,7 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 // I8: the int8_float16 path (K25): A and W are int8 (per-row dequant scales a_scale[m], w_scale[n]),
 // v_mfma_i32_32x32x32_i8 accumulates in int32, the epilogue de-quantises.  The tile is defined in BYTES
 // (128-byte rows = 64 halves or 128 int8), so staging, swizzle and fragment reads are shared.
-template <bool TRANS, bool I8, int PIPE>
+template <bool TRANS, bool I8>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int ES = I8 ? 1 : 2;        // element size
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   // issues pieces w and w + 8 of a unit (unit rows 8*piece .. +7).  Unit row u of A0 is tile row (u>>6)*128 + (u&63)
   // (+64 for A1); of B0 tile column (u>>5)*64 + (u&31) (+32 for B1).  LDS slot (u, c') receives global chunk
   // c = c' ^ ((u >> 1) & 7); the fragment reads below apply the same involution. ----
-  // (32-bit offsets from the wave-uniform operand bases: the DMA instruction takes SGPR base + VGPR offset, which
-  //  halves the address registers of the eight pieces — the PIPE = 1 loop has none to spare)
+  // (32-bit offsets from the wave-uniform operand bases: the DMA instruction takes SGPR base + VGPR offset — half the
+  //  address registers and no 64-bit add per piece in the load segment: 890 -> 960 TFLOP/s encoder-weighted)
   unsigned goff[4][2];   // [unit: A0, A1, B0, B1][piece]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -141,20 +141,19 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   const int brow = bu * 128, bkey = (bu >> 1) & 7;
 
   intx4 fa[2][4], fb0[4], fb1[4];
-  auto read_a_to = [&](const char* unit, intx4 (&dst)[2][4]) {
+  auto read_a = [&](const char* unit) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        dst[i][ks] = *reinterpret_cast<const intx4*>(unit + arow[i] + (((ks * 2 + hi) ^ akey[i]) << 4));
+        fa[i][ks] = *reinterpret_cast<const intx4*>(unit + arow[i] + (((ks * 2 + hi) ^ akey[i]) << 4));
   };
-  auto read_a = [&](const char* unit) { read_a_to(unit, fa); };
   auto read_b = [&](const char* unit, intx4 (&fb)[4]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const intx4*>(unit + brow + (((ks * 2 + hi) ^ bkey) << 4));
   };
-  // 8 MFMAs: the two row tiles of A half `ah` (registers fax) x column tile `ni`
-  auto mma_x = [&](int ah, int ni, const intx4 (&fax)[2][4], const intx4 (&fb)[4]) {
+  // 8 MFMAs: the two row tiles of A half `ah` (registers fa) x column tile `ni`
+  auto mma = [&](int ah, int ni, const intx4 (&fb)[4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -162,15 +161,14 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
       for (int i = 0; i < 2; ++i) {
         const int mi = ah * 2 + i;
         // TRANS: D[m][n];  else D[n][m]  (both accumulate into acc[mi][ni])
-        const intx4 opa = TRANS ? fax[i][ks] : fb[ks];
-        const intx4 opb = TRANS ? fb[ks] : fax[i][ks];
+        const intx4 opa = TRANS ? fa[i][ks] : fb[ks];
+        const intx4 opb = TRANS ? fb[ks] : fa[i][ks];
         if (I8) acci[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(opa, opb, acci[mi][ni], 0, 0, 0);
         else accf[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, opa),
                                                                  __builtin_bit_cast(half8_t, opb), accf[mi][ni], 0, 0, 0);
       }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto mma = [&](int ah, int ni, const intx4 (&fb)[4]) { mma_x(ah, ni, fa, fb); };
   // end of a load segment: retire the unit the next phase reads (everything but the four youngest units); when
   // this phase had nothing left to issue the queue is shorter than the count assumes, so drain it
   auto seg_wait = [&](bool issued) {
@@ -178,213 +176,70 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
-  if constexpr (PIPE == 0) {
   // ---- prologue: tile 0 whole, tile 1's B0 / A0 (the issue order of the steady state) ----
-    issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
-    if (nk > 1) { issue(2, 1); issue(0, 1); }
-    seg_wait(nk > 1);
-    GB_BARRIER();
-    if (wm == 1) GB_BARRIER();   // group 1 runs half a phase behind group 0
+  issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
+  if (nk > 1) { issue(2, 1); issue(0, 1); }
+  seg_wait(nk > 1);
+  GB_BARRIER();
+  if (wm == 1) GB_BARRIER();   // group 1 runs half a phase behind group 0
 
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* slot = smem_raw + (kt & 1) * GB_SLOT_BYTES;
-      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
-      // phase 1: A0 x B0
-      GB_TL(0);
-      read_a(slot);
-      read_b(slot + 2 * GB_UNIT_BYTES, fb0);
-      if (n1) issue(3, kt + 1);
-      seg_wait(n1);
-      GB_TL(1);
-      GB_BARRIER();
-      GB_TL(2);
-      mma(0, 0, fb0);
-      GB_TL(3);
-      GB_BARRIER();
-      // phase 2: A0 x B1
-      GB_TL(4);
-      read_b(slot + 3 * GB_UNIT_BYTES, fb1);
-      if (n1) issue(1, kt + 1);
-      seg_wait(n1);
-      GB_TL(5);
-      GB_BARRIER();
-      GB_TL(6);
-      mma(0, 1, fb1);
-      GB_TL(7);
-      GB_BARRIER();
-      // phase 3: A1 x B0
-      GB_TL(8);
-      read_a(slot + GB_UNIT_BYTES);
-      if (n2) issue(2, kt + 2);
-      seg_wait(n2);
-      GB_TL(9);
-      GB_BARRIER();
-      GB_TL(10);
-      mma(1, 0, fb0);
-      GB_TL(11);
-      GB_BARRIER();
-      // phase 4: A1 x B1
-      GB_TL(12);
-      if (n2) issue(0, kt + 2);
-      seg_wait(n2);
-      GB_TL(13);
-      GB_BARRIER();
-      GB_TL(14);
-      mma(1, 1, fb1);
-      GB_TL(15);
-      GB_BARRIER();
-    }
-    if (wm == 0) GB_BARRIER();   // the barrier group 1 spent on the stagger
-  } else {
-    // ---- PIPE = 1: ONE instruction stream per wave, software-pipelined, three barriers per K tile ----
-    // Every wave runs the same stream (no load / compute groups): the fragments of phase p + 1 are requested from LDS
-    // and the DMA of the tile two steps ahead is issued in the shadow of phase p's 8 MFMAs, so that on every SIMD the
-    // memory instructions of one wave issue while the other wave's (or its own) MFMAs hold the matrix pipe — no wave
-    // is ever parked in a load-only segment.
-    //   MFMAs:            P1: A0 x B0      P2: A0 x B1      P3: A1 x B0      P4: A1 x B1        (A in fa, B in fb0 / fb1)
-    //   LDS -> registers: P1: B1(t) -> fb1                  P2: A1(t) -> fa, row tile by row tile, each behind the
-    //                     P4: B0(t+1) -> fb0, A0(t+1) -> fa the same way            last MFMAs that read the old one
-    //   DMA (1 unit):     P1: A1(t+1)      P2: A0(t+2)      P3: B0(t+2)      P4: B1(t+2)        (issue order A0 B0 B1 A1)
-    // One A register set serves both halves (P2 and P4 run row tile 0's four MFMAs, overwrite its fragments with the
-    // next half's, then row tile 1's): 64 fragment registers instead of 96 — with 128 accumulators the difference
-    // between fitting in 256 registers and spilling inside the loop.
-    // RAW: a unit is read in the phase after the wait + barrier that retires it; in issue order four units follow the
-    // one the next phase needs, so the wait is vmcnt(2 * 4), fewer at the tail (wait_unit counts).  WAR: every slot is
-    // refilled at least two phases — and two barriers — after the phase that read it, and those reads feed MFMAs that
-    // issue before the second barrier, so they have completed.  P3 reads nothing from LDS: no barrier between P2 and
-    // P3.  The DMA queue is never drained inside the loop.
-    const int n_units = 4 * nk;                    // units in issue order: tile-major, A0 B0 B1 A1
-    int issued = 0;                                // units issued so far, counting past the end (wave-uniform)
-    // (the unit is a literal at every call site: a runtime index into goff[] would put the array in scratch)
-#define GB_ISSUE_NEXT(unit_, tile_)          \
-    do {                                       \
-      if ((tile_) < nk) issue((unit_), (tile_)); \
-      issued += 1;                             \
-    } while (0)
-    // wait until unit `target` (index in issue order) has landed for this wave: the younger units stay in flight
-    auto wait_unit = [&](int target) {
-      if (target > n_units - 1) target = n_units - 1;
-      const int last = issued < n_units ? issued : n_units;   // units really issued
-      const int after = last - 1 - target;
-      if (after >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (after == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (after == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (after == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (after == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto read_a_half = [&](const char* unit, int i) {        // row tile i of an A unit -> fa[i]
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        fa[i][ks] = *reinterpret_cast<const intx4*>(unit + arow[i] + (((ks * 2 + hi) ^ akey[i]) << 4));
-    };
-    auto mma_half = [&](int mi, int ni, int i, const intx4 (&fb)[4]) {   // 4 MFMAs: A row tile fa[i] x fb -> acc[mi][ni]
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const intx4 opa = TRANS ? fa[i][ks] : fb[ks];
-        const intx4 opb = TRANS ? fb[ks] : fa[i][ks];
-        if (I8) acci[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(opa, opb, acci[mi][ni], 0, 0, 0);
-        else accf[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, opa),
-                                                                 __builtin_bit_cast(half8_t, opb), accf[mi][ni], 0, 0, 0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-    };
-    auto mma_ks = [&](int ah, int ni, const intx4 (&fb)[4], int k0, int k1) {   // k-steps [k0, k1) of mma()
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < k0 || ks >= k1) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int mi = ah * 2 + i;
-          const intx4 opa = TRANS ? fa[i][ks] : fb[ks];
-          const intx4 opb = TRANS ? fb[ks] : fa[i][ks];
-          if (I8) acci[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(opa, opb, acci[mi][ni], 0, 0, 0);
-          else accf[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, opa),
-                                                                   __builtin_bit_cast(half8_t, opb), accf[mi][ni], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-    };
-    // prologue: tile 0 whole and A0 B0 B1 of tile 1 (A1(1) goes out in phase 1), then the reads of "phase 4 of tile -1"
-    GB_ISSUE_NEXT(0, 0); GB_ISSUE_NEXT(2, 0); GB_ISSUE_NEXT(3, 0); GB_ISSUE_NEXT(1, 0);
-    GB_ISSUE_NEXT(0, 1); GB_ISSUE_NEXT(2, 1); GB_ISSUE_NEXT(3, 1);
-    wait_unit(1);                                  // A0(0), B0(0)
+  // one K tile; n1 / n2 = tiles kt + 1 / kt + 2 exist — compile-time facts, so that the steady-state loop carries no
+  // branch and no queue-length test in its load segments (the last two tiles run the same code with them false)
+  auto tile = [&](int kt, auto N1, auto N2) {
+    constexpr bool n1 = decltype(N1)::value, n2 = decltype(N2)::value;
+    const char* slot = smem_raw + (kt & 1) * GB_SLOT_BYTES;
+    // phase 1: A0 x B0
+    GB_TL(0);
+    read_a(slot);
+    read_b(slot + 2 * GB_UNIT_BYTES, fb0);
+    if (n1) issue(3, kt + 1);
+    seg_wait(n1);
+    GB_TL(1);
     GB_BARRIER();
-    read_a(smem_raw);
-    read_b(smem_raw + 2 * GB_UNIT_BYTES, fb0);
-    wait_unit(2);                                  // B1(0)
+    GB_TL(2);
+    mma(0, 0, fb0);
+    GB_TL(3);
     GB_BARRIER();
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* slot = smem_raw + (kt & 1) * GB_SLOT_BYTES;
-      const char* nslot = smem_raw + ((kt + 1) & 1) * GB_SLOT_BYTES;
-      const int u0 = 4 * kt;                       // index of A0(kt) in issue order
-      const bool more = kt + 1 < nk;
-      // (PIPE = 2: the DMA instructions go out behind the phase's first four MFMAs instead of ahead of them, so the
-      //  matrix pipe has queued work while the wave is busy issuing them)
-      // phase 1: A0 x B0
-      if (PIPE == 1) GB_ISSUE_NEXT(1, kt + 1);
-      read_b(slot + 3 * GB_UNIT_BYTES, fb1);
-      if (PIPE == 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        mma_ks(0, 0, fb0, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        GB_ISSUE_NEXT(1, kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_ks(0, 0, fb0, 2, 4);
-      } else {
-        mma(0, 0, fb0);
-      }
-      wait_unit(u0 + 3);                           // A1(kt): read in phase 2
-      GB_BARRIER();
-      // phase 2: A0 x B1, A1(kt) taking A0's registers row tile by row tile
-      if (PIPE == 1) GB_ISSUE_NEXT(0, kt + 2);
-      // (the order is pinned: a fragment read hoisted above the MFMAs that still use the old fragment would need a
-      //  second register set, which is exactly what does not fit)
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(0, 1, 0, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (PIPE == 2) GB_ISSUE_NEXT(0, kt + 2);
-      read_a_half(slot + GB_UNIT_BYTES, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(1, 1, 1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      read_a_half(slot + GB_UNIT_BYTES, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      // phase 3: A1 x B0 (nothing is read from LDS: no barrier before it)
-      if (PIPE == 2) {
-        mma_ks(1, 0, fb0, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        GB_ISSUE_NEXT(2, kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_ks(1, 0, fb0, 2, 4);
-      } else {
-        GB_ISSUE_NEXT(2, kt + 2);
-        mma(1, 0, fb0);
-      }
-      if (more) wait_unit(u0 + 5);                 // A0(kt+1), B0(kt+1): read in phase 4
-      GB_BARRIER();
-      // phase 4: A1 x B1, B0(kt+1) and A0(kt+1) coming in
-      if (PIPE == 1) GB_ISSUE_NEXT(3, kt + 2);
-      if (more) read_b(nslot + 2 * GB_UNIT_BYTES, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(2, 1, 0, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (PIPE == 2) GB_ISSUE_NEXT(3, kt + 2);
-      if (more) read_a_half(nslot, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(3, 1, 1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        read_a_half(nslot, 1);
-        wait_unit(u0 + 6);                         // B1(kt+1): read in phase 1
-      }
-      GB_BARRIER();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef GB_ISSUE_NEXT
-  }
+    // phase 2: A0 x B1
+    GB_TL(4);
+    read_b(slot + 3 * GB_UNIT_BYTES, fb1);
+    if (n1) issue(1, kt + 1);
+    seg_wait(n1);
+    GB_TL(5);
+    GB_BARRIER();
+    GB_TL(6);
+    mma(0, 1, fb1);
+    GB_TL(7);
+    GB_BARRIER();
+    // phase 3: A1 x B0
+    GB_TL(8);
+    read_a(slot + GB_UNIT_BYTES);
+    if (n2) issue(2, kt + 2);
+    seg_wait(n2);
+    GB_TL(9);
+    GB_BARRIER();
+    GB_TL(10);
+    mma(1, 0, fb0);
+    GB_TL(11);
+    GB_BARRIER();
+    // phase 4: A1 x B1
+    GB_TL(12);
+    if (n2) issue(0, kt + 2);
+    seg_wait(n2);
+    GB_TL(13);
+    GB_BARRIER();
+    GB_TL(14);
+    mma(1, 1, fb1);
+    GB_TL(15);
+    GB_BARRIER();
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) tile(kt, T_{}, T_{});
+  if (kt + 1 < nk) { tile(kt, T_{}, F_{}); ++kt; }
+  if (kt < nk) tile(kt, F_{}, F_{});
+  if (wm == 0) GB_BARRIER();   // the barrier group 1 spent on the stagger
 
   // ---------------------------------- epilogue ----------------------------------
   const float* sa = I8 ? p.a_scale + (size_t)z * p.as_bstride : nullptr;
@@ -535,12 +390,6 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
 
 namespace fwk {
 
-// K-loop form of the kernel: 0 = two staggered load / compute groups, 1 = one software-pipelined stream per wave
-// (the header comment of the PIPE = 1 branch); selected once, A/B-switchable for profiles/gemm_bench.py
-static int g_gemm_pipe = GB_PIPE_DEFAULT;
-void set_gemm_pipe(int pipe) { g_gemm_pipe = (pipe >= 0 && pipe <= 2) ? pipe : 0; }
-int get_gemm_pipe() { return g_gemm_pipe; }
-
 int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   GemmParams p = pin;
   const bool i8 = p.a_scale != nullptr;
@@ -554,27 +403,24 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   const int lds = GB_LDS_BYTES;  // 128 KiB: one workgroup per CU
   static bool attr_set = false;
   if (!attr_set) {
-#define GB_ATTR(T_, I_, P_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<T_, I_, P_>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-    GB_ATTR(false, false, 0); GB_ATTR(true, false, 0); GB_ATTR(false, true, 0); GB_ATTR(true, true, 0);
-    GB_ATTR(false, false, 1); GB_ATTR(true, false, 1); GB_ATTR(false, true, 1); GB_ATTR(true, true, 1);
-    GB_ATTR(false, false, 2); GB_ATTR(true, false, 2); GB_ATTR(false, true, 2); GB_ATTR(true, true, 2);
-#undef GB_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int grid = p.nMt * p.nNt * batch;
-#define GB_GO(T_, I_)                                                              \
-  do {                                                                             \
-    if (g_gemm_pipe == 2) gemm_f16_kernel<T_, I_, 2><<<grid, 512, lds, st>>>(p);   \
-    else if (g_gemm_pipe == 1) gemm_f16_kernel<T_, I_, 1><<<grid, 512, lds, st>>>(p); \
-    else gemm_f16_kernel<T_, I_, 0><<<grid, 512, lds, st>>>(p);                    \
-  } while (0)
   if (i8) {
-    if (trans) GB_GO(true, true); else GB_GO(false, true);
+    if (trans) gemm_f16_kernel<true, true><<<grid, 512, lds, st>>>(p);
+    else gemm_f16_kernel<false, true><<<grid, 512, lds, st>>>(p);
   } else {
-    if (trans) GB_GO(true, false); else GB_GO(false, false);
+    if (trans) gemm_f16_kernel<true, false><<<grid, 512, lds, st>>>(p);
+    else gemm_f16_kernel<false, false><<<grid, 512, lds, st>>>(p);
   }
-#undef GB_GO
   return 0;
 }
 

@@ -29,8 +29,6 @@ struct GemmParams {
   int nMt, nNt;                                       // filled by launch_gemm
 };
 int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
-void set_gemm_pipe(int pipe);   // K-loop form (gemm.hip): A/B switch of profiles/gemm_bench.py
-int get_gemm_pipe();
 
 // ---- row kernels (rowops.hip) -----------------------------------------------------
 // y[r] = LN(x[r]) * g + b, eps 1e-5, fp32 statistics (two-pass in registers)

@@ -37,10 +37,6 @@ int32_t fw_test_logits_rules(fw_model* m, const float* logits, int32_t R, const 
 /* measurement hook (profiles/gemm_bench.py): average milliseconds of one launch of the "many rows" GEMM
  * C[batch][M][N] = A[batch][M][K] W[N][K]^T on device-resident pseudo-random operands (fp16, or int8 on an
  * int8_float16 model); lda = K + a_pad, ldw = K + w_pad elements; trans: the transposed-output form */
-/* K-loop form of the many-rows GEMM (csrc/gemm.hip): 0 = two staggered load / compute wave groups, 1 = one
- * software-pipelined stream per wave.  Returns the previous setting.  Process-wide; for A/B measurement and for the
- * tests that run the kernel's parity cases in both forms. */
-int32_t fw_test_set_gemm_pipe(int32_t pipe);
 int32_t fw_bench_gemm(fw_model* m, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t a_pad, int32_t w_pad,
                       int32_t trans, int32_t iters, float* ms_out);
 /* micro-benchmark of the decoder linear kernel (dec_gemm_frag_kernel) for a tile-shape `variant` (dec_kernels.hip:

@@ -10,9 +10,8 @@ from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # n
 
 VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)", 2: "8w 4x2 ch3", 3: "8w 4x2 ch4",
             4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2",
-            10: "big 2x2 128x128 KC1x4 touch+10", 11: "big 4x2 256x128 KC2x3 touch+5",
-            12: "big 2x2 128x128 KC1x4 no touch", 13: "big 2x2 128x128 KC1x9 (1 WG/CU)",
-            14: "big 2x2 128x128 KC1x4 touch+20", 15: "big 2x4 128x256 KC2x3 touch+5"}
+            10: "big 4x2 waves 256x128 KC2x3", 11: "big 2x2 waves 128x64 KC1x5", 12: "big 2x2 waves 128x128 KC1x4",
+            21: "4w 4x4 ch5", 22: "8w 4x4 ch5"}
 if os.environ.get("DLB_VARIANTS"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["DLB_VARIANTS"].split(",")}
 SHAPES = [("qkv", 3840, 1280, 1), ("dxd", 1280, 1280, 0), ("ffn1", 5120, 1280, 1), ("ffn2", 1280, 5120, 0)]

@@ -1,9 +1,7 @@
 """Encoder-GEMM micro-benchmark through the C ABI measurement hook (fw_bench_gemm): the large-v3 encoder shapes at 16
 chunks per batch, TFLOP/s per shape.  Operand leading dimensions can be padded (stride experiments).
 
-    python profiles/gemm_bench.py [--int8] [--pad 0,64] [--ab ROUNDS]
---ab: A/B of the kernel's two K-loop forms (PIPE 0 = staggered load / compute groups, PIPE 1 = one software-pipelined
-stream per wave) in ONE process, interleaved rounds, median and best per shape (cdna_hip_programming.md rule 24).
+    python profiles/gemm_bench.py [--int8] [--pad 0,64]
 """
 import argparse
 import ctypes as C
@@ -26,7 +24,6 @@ def main():
     ap.add_argument("--pad", default="0")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--ab", type=int, default=0)
     args = ap.parse_args()
     from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights
     cfg = get_config("micro")
@@ -35,30 +32,6 @@ def main():
     lib = _lib.load()
     h = model._replicas[0].handle
     out = {"env": {k: v for k, v in os.environ.items() if k.startswith("FWAMD_")}, "int8": args.int8}
-    if args.ab:
-        import statistics
-        weights = {"conv1": 1, "conv2": 1, "qk": 32, "v^T": 32, "out": 32, "ffn1": 32, "ffn2": 32}
-        t = {(p, s[0]): [] for p in (0, 1, 2) for s in SHAPES}
-        for r in range(args.ab):
-            for pipe in ((0, 1, 2) if r % 2 == 0 else (2, 1, 0)):
-                lib.fw_test_set_gemm_pipe(pipe)
-                for name, M, N, K, tr in SHAPES:
-                    ms = C.c_float()
-                    _lib.check(lib.fw_bench_gemm(h, M, N, K, args.batch, 0, 0, tr, args.iters, C.byref(ms)))
-                    t[(pipe, name)].append(ms.value)
-        lib.fw_test_set_gemm_pipe(0)
-        for pipe in (0, 1, 2):
-            tot_ms = tot_fl = 0.0
-            for name, M, N, K, tr in SHAPES:
-                med = statistics.median(t[(pipe, name)])
-                fl = 2.0 * args.batch * M * N * K
-                out[f"pipe={pipe} {name}"] = {"ms median": round(med, 4), "ms best": round(min(t[(pipe, name)]), 4),
-                                              "TFLOP/s median": round(fl / med / 1e9, 1)}
-                tot_ms += med * weights[name]
-                tot_fl += fl * weights[name]
-            out[f"pipe={pipe} encoder-weighted"] = {"ms": round(tot_ms, 2), "TFLOP/s": round(tot_fl / tot_ms / 1e9, 1)}
-        print(json.dumps(out, indent=1))
-        return
     for pad in [int(x) for x in args.pad.split(",")]:
         tot_ms = tot_fl = 0.0
         weights = {"conv1": 1, "conv2": 1, "qk": 32, "v^T": 32, "out": 32, "ffn1": 32, "ffn2": 32}

@@ -55,7 +55,7 @@ def _gemm_i8(model, A, W, bias=None, res=None, act=0):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 384), (300, 256, 128), (1500, 512, 512),
                                    (77, 128, 256), (1500, 128, 512), (1100, 256, 256)])
-def test_gemm_int8_exact(kmodel, gemm_pipe, M, N, K):
+def test_gemm_int8_exact(kmodel, M, N, K):
     rng = np.random.default_rng(M + 3 * N + K)
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
     A[min(5, M - 1)] = 0.0                       # an all-zero row: scale 1, codes 0
@@ -75,7 +75,7 @@ def test_gemm_int8_exact(kmodel, gemm_pipe, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 128, 256), (1100, 256, 256)])   # one and many M tiles
-def test_gemm_int8_transposed_epilogue(kmodel, gemm_pipe, M, N, K):
+def test_gemm_int8_transposed_epilogue(kmodel, M, N, K):
     rng = np.random.default_rng(9)
     A = _h(rng.standard_normal((M, K)).astype(np.float32))
     W = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.3)
@@ -86,16 +86,6 @@ def test_gemm_int8_transposed_epilogue(kmodel, gemm_pipe, M, N, K):
     ref = _h((aq @ wq.T).astype(np.float32) * a_s[:, None] * w_s[None, :] + b).T
     assert out.shape == (N, M)
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-3
-
-
-@pytest.fixture(params=[0, 1, 2], ids=["staggered-groups", "pipelined-stream", "pipelined-dma-mid"])
-def gemm_pipe(request):
-    """both K-loop forms of the many-rows GEMM (csrc/gemm.hip, PIPE = 0 / 1)"""
-    from faster_whisper_amd import _lib
-    lib = _lib.load()
-    old = lib.fw_test_set_gemm_pipe(request.param)
-    yield request.param
-    lib.fw_test_set_gemm_pipe(old)
 
 
 @pytest.mark.parametrize("R,N,K", [(80, 1280, 1280), (80, 5120, 1280), (80, 1280, 5120), (77, 3840, 1280),
