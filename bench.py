@@ -115,6 +115,8 @@ def build_backend(args, cfg, rank, world, local_rank):
     ct = 1 if args.compute_type == "int8_float16" else 0
     common = dict(device="cuda", device_index=local_rank, max_batch_size=args.batch, max_beam_size=args.beam,
                   inter_threads=args.workers, compute_type=args.compute_type)
+    if getattr(args, "merge_fill", None) is not None:
+        common["merge_fill_percent"] = args.merge_fill
     weights = None
     if world > 1:
         blob = None
@@ -157,6 +159,8 @@ def parse_args(argv=None):
                          "weights, shared decode group).  The merged decode run grows with the batches in flight "
                          "and every decoder weight is streamed once per run: measured 6: 2 221x, 8: 2 405x, 12: 2 523x, "
                          "16: 2 595x, 20: 2 740x, 24: 2 765x, 32: 2 834x (decode workspace clamped to 336 chunks by HBM)")
+    ap.add_argument("--merge-fill", type=int, default=None,
+                    help="share (percent) of a decode run's chunk capacity the leader of a run waits for (backend default 90)")
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
                     help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
     ap.add_argument("--word-timestamps", action="store_true",

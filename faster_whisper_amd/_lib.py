@@ -73,7 +73,7 @@ SYMBOLS = [
     "fw_generate", "fw_detect_language", "fw_align",
     "fw_prof_enable", "fw_prof_reset", "fw_prof_count", "fw_prof_name", "fw_prof_get", "fw_synchronize",
     "fw_dev_alloc", "fw_dev_free", "fw_dev_upload",
-    "fw_test_gemm", "fw_test_layernorm", "fw_test_attention", "fw_test_dec_linear", "fw_test_dec_logits", "fw_test_logits_rules", "fw_bench_gemm", "fw_bench_dec_linear",
+    "fw_test_gemm", "fw_test_layernorm", "fw_test_attention", "fw_test_dec_linear", "fw_test_dec_logits", "fw_test_logits_rules", "fw_bench_gemm", "fw_bench_dec_linear", "fw_bench_attention",
     "fw_vad_create", "fw_vad_forward", "fw_vad_free", "fw_vad_forward_dev",
 ]
 
@@ -109,7 +109,7 @@ def load():
     lib.fw_model_decode_batch.argtypes = [vp]
     lib.fw_model_decode_batch.restype = i32
     lib.fw_model_join_decoder.argtypes = [vp, vp]
-    lib.fw_model_set_merge_wait.argtypes = [vp, i32]
+    lib.fw_model_set_merge_wait.argtypes = [vp, i32, i32]
     lib.fw_model_decode_stats.argtypes = [vp, i64p, i64p, i64p, i32p]
     lib.fw_pack_blob_size.argtypes = [C.POINTER(FwConfig), C.POINTER(FwWeight), i32, i32, i64p, C.POINTER(vp)]
     lib.fw_pack_blob_copy.argtypes = [vp, vp, i64]
@@ -144,6 +144,7 @@ def load():
     lib.fw_test_dec_linear.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.fw_test_dec_logits.argtypes = [vp, vp, i32, vp]
     lib.fw_test_logits_rules.argtypes = [vp, vp, i32, vp, i32, vp, C.POINTER(FwGenOpts), i32, vp, vp]
+    lib.fw_bench_attention.argtypes = [vp, i32, i32, i32, i32, i32, f32p]
     lib.fw_bench_gemm.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, f32p]
     lib.fw_bench_dec_linear.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32p]
     lib.fw_test_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp]

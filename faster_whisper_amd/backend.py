@@ -256,6 +256,7 @@ class Whisper:
         # merge_wait_ms: how long the leader of a decode run waits for workers that are still encoding
         # (fwamd.h: fw_model_set_merge_wait; None = one encoder pass, 0 = never: lowest latency per call)
         merge_wait_ms = kwargs.pop("merge_wait_ms", None)
+        merge_fill = kwargs.pop("merge_fill_percent", None)
         for i in idx:
             primary = _Replica(cfg, weights, ct, i, max_batch_size, max_beam_size, blob_dev)
             self._replicas.append(primary)
@@ -269,8 +270,9 @@ class Whisper:
                     if decode_group:
                         _lib.check(self._lib.fw_model_join_decoder(r.handle, primary.handle))
                     self._replicas.append(r)
-            if merge_wait_ms is not None:
-                _lib.check(self._lib.fw_model_set_merge_wait(primary.handle, int(merge_wait_ms)))
+            if merge_wait_ms is not None or merge_fill is not None:
+                _lib.check(self._lib.fw_model_set_merge_wait(primary.handle, -1 if merge_wait_ms is None else int(merge_wait_ms),
+                                                             90 if merge_fill is None else int(merge_fill)))
         self._seed_counter = itertools.count(1)
         self._rr = itertools.count()
         self._tls = threading.local()

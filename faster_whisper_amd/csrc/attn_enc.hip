@@ -17,7 +17,11 @@
 //    V^T tile: rows padded to 136 bytes (conflict-free ds_read_b64).
 //  * register-staged double buffering: next tile's global loads are issued before
 //    the MFMA/softmax block, written to LDS after it; one barrier per 64-key tile.
-//  * online softmax in fp32 with exp2 (scores pre-multiplied by log2 e).
+//  * online softmax in fp32 with exp2.  The vector pipe, not the matrix pipe, is what bounds this kernel (per 64-key
+//    tile and wave: 16 MFMAs = 512 matrix cycles against, originally, ~210 vector instructions), so the softmax is
+//    written for the fewest vector instructions: log2 e / 8 is folded into the Q fragment once (no per-score scaling),
+//    the tile maximum uses 3-input max, the running accumulator is rescaled only when the maximum actually moved (a
+//    wave-uniform branch; for most tiles after the first few it does not), and P is converted to fp16 two at a time.
 #include "common.h"
 #include "kernels.h"
 
@@ -41,7 +45,8 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
   const half_t* kb = k + (size_t)b * qk_bstride + h * 64;
   const half_t* vb = vt + (size_t)b * vt_bstride + (size_t)(h * 64) * ldvt;
 
-  // Q fragment (B operand): query row l31 of this wave, d = ks*16 + hi*8 .. +7, pre-scaled by 1/8
+  // Q fragment (B operand): query row l31 of this wave, d = ks*16 + hi*8 .. +7, pre-scaled by log2(e) / 8 (fp32 product,
+  // one rounding to fp16): the scores come out of the MFMA in the exp2 domain
   half8_t qf[4];
   {
     int qr = q0 + wave * 32 + l31;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
     for (int ks = 0; ks < 4; ++ks) {
       half8_t v = *reinterpret_cast<const half8_t*>(qp + ks * 16);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * (0.125f * 1.4426950408889634f));
       qf[ks] = v;
     }
   }
@@ -87,7 +92,6 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
 
   floatx16 o[2] = {floatx16{0}, floatx16{0}};
   float m_run = -1.0e30f, l_run = 0.f;
-  const float LOG2E = 1.4426950408889634f;
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
@@ -109,37 +113,40 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
     // ---- online softmax (one query per lane; partner lane^32 holds the other keys) ----
     const int kbase = kt * AE_KV + 4 * hi;
     const bool tail = (kt * AE_KV + AE_KV) > T;
-    float mx = -1.0e30f;
+    if (tail) {
 #pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2)
+      for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kb2][r] * LOG2E;
-        if (tail) {
+        for (int r = 0; r < 16; ++r) {
           const int key = kbase + kb2 * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= T) v = -1.0e30f;
+          if (key >= T) s[kb2][r] = -1.0e30f;
         }
-        s[kb2][r] = v;
-        mx = fmaxf(mx, v);
-      }
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[0][r]), s[1][r]);   // -> v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // rescale only when some query of the wave saw a larger score (wave-uniform: no divergence)
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb2][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(s[kb2][r] - m_run);
         s[kb2][r] = pv;
         psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T[dh][query] += V^T[dh][key] * P^T[key][query] ----
 #pragma unroll
@@ -148,7 +155,10 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         half8_t pf;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = (half_t)s[kb2][ks2 * 8 + e];
+        for (int e = 0; e < 8; e += 2) {   // v_cvt_pkrtz would truncate: round-to-nearest pairs
+          const half2_t h2 = {(half_t)s[kb2][ks2 * 8 + e], (half_t)s[kb2][ks2 * 8 + e + 1]};
+          pf[e] = h2[0]; pf[e + 1] = h2[1];
+        }
         const int koff = kb2 * 32 + ks2 * 16 + 4 * hi;  // keys koff+{0..3}, koff+8+{0..3}
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -189,6 +199,7 @@ void launch_attn_enc(hipStream_t st, const half_t* q, const half_t* k, int64_t l
                      const half_t* vt, int64_t ldvt, int64_t vt_bstride, half_t* out, int64_t ldo,
                      int64_t o_bstride, int B, int H, int T) {
   dim3 grid((T + AE_Q - 1) / AE_Q, H, B);
+  // (132 registers: 3 waves per SIMD.  Forcing 4 with __launch_bounds__(256, 4) spills and measured 6 % slower.)
   attn_enc_kernel<<<grid, 256, 0, st>>>(q, k, ld, qk_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, T);
 }
 }  // namespace fwk

@@ -41,6 +41,10 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                            int N, int K, int act);
+// ... with an explicit tile grouping (1: one 16 x 16 tile per workgroup, 2: 2 x 2 tiles)
+int launch_dec_gemm_skinny_tiles(hipStream_t st, int tiles, const half_t* xf, const half_t* Wf, const half_t* bias,
+                                 const float* s1, const float* cf, const half_t* res, int ldr, half_t* out, int ldo,
+                                 half_t* out_frag, int R, int N, int K, int act);
 // the GEMM-shaped kernel of merged runs whatever the row count, workgroup shape cfg (dec_kernels.hip); same bits
 int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,

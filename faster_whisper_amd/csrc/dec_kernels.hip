@@ -1510,6 +1510,10 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 7: frag_variant<8, 2, 4, 3>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 8: frag_variant<8, 8, 2, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 9: frag_variant<4, 4, 4, 2>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 23: frag_variant<4, 1, 1, 10>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 24: frag_variant<8, 1, 1, 10>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 25: frag_variant<4, 1, 2, 6>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
+    case 26: frag_variant<8, 1, 2, 6>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 21: frag_variant<4, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 22: frag_variant<8, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 10: case 11: case 12:
@@ -1541,10 +1545,37 @@ int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, c
                            int N, int K, int act) {
   if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
   const int waves = K >= 2560 ? 8 : 4;   // keeps a wave's share at <= 20 k-steps = 2 chunks of loads
-  // 2 x 2 tiles also for the merged runs (R up to 640): 4 x 2, 2 x 4, 4 x 4 tiles and 8 waves for every K measured
-  // 2 135 / 2 200 / 1 937 / 2 264x against 2 304x (round 2, profiles/README.md)
+  // Tile grouping by row count (the arithmetic of an output does not depend on it: same bits).  One 16 x 16 tile per
+  // workgroup when there are few rows — twice to four times the workgroups streaming the weights, a wave's whole K share
+  // in flight at once: single utterance (5 rows) 41.8 -> 31.4 us per layer, and at a solo batch (80 rows) for the
+  // linears with 1280 columns (5.6 -> 4.4, 12.1 -> 10.0 us); 2 x 2 tiles otherwise, also for merged runs below
+  // DEC_BIG_MIN_ROWS (4 x 2, 2 x 4, 4 x 4 tiles measured no better there: profiles/r03_dec_linear_bench.txt, README.md)
+  const bool one_tile = R <= 16 || (R <= 96 && N <= 1280);
+  if (one_tile) {
+    if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    return 0;
+  }
   if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
   else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  return 0;
+}
+
+// the register-streaming kernel with an explicit tile grouping (tests: every grouping returns the same bits)
+int launch_dec_gemm_skinny_tiles(hipStream_t st, int tiles, const half_t* xf, const half_t* Wf, const half_t* bias,
+                                 const float* s1, const float* cf, const half_t* res, int ldr, half_t* out, int ldo,
+                                 half_t* out_frag, int R, int N, int K, int act) {
+  if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
+  const int waves = K >= 2560 ? 8 : 4;
+  if (tiles == 1) {
+    if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  } else if (tiles == 2) {
+    if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  } else {
+    return -1;
+  }
   return 0;
 }
 

@@ -722,13 +722,15 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     const int cap = std::max(dm->decode_batch, dm->max_batch);
     int wait_ms = grp.merge_wait_ms.load();
     if (wait_ms < 0) wait_ms = std::min(120, std::max(5, (grp.enc_pass_us.load() * 5 / 4 + 999) / 1000));
+    const int fill_pct = grp.merge_fill_pct.load();
     if (cap > dm->max_batch && wait_ms > 0 && !grp.queue.front()->sampling) {
       // (waiting for a quarter, a half or the whole workspace measured the same throughput within 1 %:
       //  profiles/r02_mid_*; one half keeps two runs alternating, so encoders and result handling overlap a run)
       for (;;) {
         int queued = 0;
         for (const GenRequest* r : grp.queue) queued += r->B;
-        if (queued * 2 >= cap || grp.encoding.load() <= 0) break;
+        const int64_t want = std::min<int64_t>(cap, std::max<int64_t>(dm->max_batch, DEC_RUN_MAX_ROWS / std::max(1, grp.queue.front()->o->beam_size)));
+        if ((int64_t)queued * 100 >= want * fill_pct || grp.encoding.load() <= 0) break;
         if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(wait_ms)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
       }

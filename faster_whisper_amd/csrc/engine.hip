@@ -1138,10 +1138,13 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   return gen_workspace_ensure(m);
 }
 
-int32_t fw_model_set_merge_wait(fw_model* fm, int32_t wait_ms) {
+int32_t fw_model_set_merge_wait(fw_model* fm, int32_t wait_ms, int32_t fill_percent) {
   FW_CHECK_ARG(fm, "null model");
   FW_CHECK_ARG(wait_ms >= -1 && wait_ms <= 10000, "merge wait: -1 (one encoder pass), 0 (never) or milliseconds <= 10000");
-  decoder_of(&fm->impl)->grp.merge_wait_ms.store(wait_ms);
+  FW_CHECK_ARG(fill_percent >= 1 && fill_percent <= 100, "merge fill: 1 .. 100 percent of a run's chunk capacity");
+  DecodeGroup& g = decoder_of(&fm->impl)->grp;
+  g.merge_wait_ms.store(wait_ms);
+  g.merge_fill_pct.store(fill_percent);
   return FW_OK;
 }
 
@@ -1654,6 +1657,7 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
   const int lr =
       use_int8 >= 10 ? fwd::launch_dec_gemm_big(st, use_int8 - 10, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
       : use_int8 == 5 ? fwd::launch_dec_gemm_skinny(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
+      : (use_int8 == 6 || use_int8 == 7) ? fwd::launch_dec_gemm_skinny_tiles(st, use_int8 - 5, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
                       : fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act);
   if (lr != 0) {
     cleanup();
@@ -1867,6 +1871,50 @@ int32_t fw_test_attention(fw_model* fm, const float* q, const float* k, const fl
   for (half_t* p : {dq, dk, dvt, dout})
     if (p) (void)hipFree(p);
   return rc;
+}
+
+// measurement hook (profiles/attn_bench.py): mean milliseconds of one launch of the encoder self-attention on
+// device-resident pseudo-random Q | K ([B][T][2d] as the fused projection leaves them) and V^T ([B][d][T padded]);
+// variant: reserved (0)
+int32_t fw_bench_attention(fw_model* fm, int32_t B, int32_t H, int32_t T, int32_t variant, int32_t iters, float* ms_out) {
+  FW_CHECK_ARG(fm && ms_out && B > 0 && H > 0 && T > 0 && iters > 0, "bad argument");
+  Model* m = &fm->impl;
+  std::lock_guard<std::mutex> lk(m->mu);
+  FW_HIP(hipSetDevice(m->device));
+  const int d = H * 64, tp = (T + 63) / 64 * 64;
+  const size_t nqk = (size_t)B * T * 2 * d, nvt = (size_t)B * d * tp, no = (size_t)B * T * d;
+  half_t *dqk = nullptr, *dvt = nullptr, *dout = nullptr;
+  int rc;
+  auto cleanup = [&]() { for (half_t* p : {dqk, dvt, dout}) if (p) (void)hipFree(p); };
+  if ((rc = dev_alloc_t(&dqk, nqk)) || (rc = dev_alloc_t(&dvt, nvt)) || (rc = dev_alloc_t(&dout, no))) { cleanup(); return rc; }
+  {
+    std::vector<uint16_t> h(std::max(nqk, nvt));
+    uint32_t sd = 777u;
+    for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = f32_to_f16_bits(((int)(sd >> 16) % 2001 - 1000) * 2e-3f); }
+    FW_HIP(hipMemcpy(dqk, h.data(), nqk * 2, hipMemcpyHostToDevice));
+    FW_HIP(hipMemcpy(dvt, h.data(), nvt * 2, hipMemcpyHostToDevice));
+  }
+  (void)variant;
+  hipEvent_t e0, e1;
+  FW_HIP(hipEventCreate(&e0));
+  FW_HIP(hipEventCreate(&e1));
+  auto go = [&]() {
+    fwk::launch_attn_enc(m->stream, dqk, dqk + d, 2 * d, (int64_t)T * 2 * d, dvt, tp, (int64_t)d * tp, dout, d, (int64_t)T * d, B,
+                         H, T);
+  };
+  go();
+  FW_HIP(hipEventRecord(e0, m->stream));
+  for (int i = 0; i < iters; ++i) go();
+  FW_HIP(hipEventRecord(e1, m->stream));
+  hipError_t he = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  cleanup();
+  if (he != hipSuccess) { set_error("attention bench failed: %s", hipGetErrorString(he)); return FW_ERUNTIME; }
+  *ms_out = ms / (float)iters;
+  return FW_OK;
 }
 
 }  // extern "C"

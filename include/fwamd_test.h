@@ -18,8 +18,9 @@ int32_t fw_test_gemm(fw_model* m, const float* A, const float* W, const float* b
  * given, GELU when act = 1, residual added last): x [R][K], W [N][K], bias [N] | NULL, res [R][N] | NULL ->
  * out [R][N] (row-major result) and out_from_frag [R][N] (the fragment-major copy the next linear reads, un-permuted
  * on the host).  use_int8 = 0: what a decode step launches for this row count; 1: the int8_float16 form (needs an
- * int8_float16 model; ln must be NULL); 5: the skinny kernel whatever the row count; 10 + cfg: the GEMM-shaped kernel of
- * merged runs (dec_gemm_big_kernel) with workgroup shape cfg, whatever the row count.  0, 5, 10.. return the same bits. */
+ * int8_float16 model; ln must be NULL); 5: the register-streaming (skinny) kernel whatever the row count, 6 / 7: that kernel with one tile / 2 x 2 tiles per
+ * workgroup; 10 + cfg: the GEMM-shaped kernel of
+ * merged runs (dec_gemm_big_kernel) with workgroup shape cfg, whatever the row count.  0, 5, 6, 7, 10.. return the same bits. */
 int32_t fw_test_dec_linear(fw_model* m, const float* x, const float* W, const float* bias, const float* ln_g,
                            const float* ln_b, const float* res, int32_t R, int32_t N, int32_t K, int32_t act,
                            int32_t use_int8, float* out, float* out_from_frag);
@@ -48,6 +49,9 @@ int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const flo
                           int32_t rows, int32_t d, float* out);
 int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,
                           int32_t B, int32_t H, int32_t T, float* out);
+/* measurement hook (profiles/attn_bench.py): mean milliseconds of one launch of the encoder self-attention kernel for
+ * B chunks x H heads x T positions on device-resident pseudo-random operands; variant is reserved (pass 0) */
+int32_t fw_bench_attention(fw_model* m, int32_t B, int32_t H, int32_t T, int32_t variant, int32_t iters, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,25 @@
+"""Encoder self-attention micro-benchmark (fw_bench_attention): large-v3 geometry, 16 chunks x 20 heads x 1500 positions.
+    python profiles/attn_bench.py"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # noqa: E402
+
+
+def main():
+    cfg = get_config("micro")
+    m = Whisper("synthetic:micro", device="cuda", files={"config": cfg, "weights": synthetic_weights(cfg, seed=1)},
+                max_batch_size=1, max_beam_size=1)
+    h = m._replicas[0].handle
+    ms = C.c_float()
+    B, H, T = 16, 20, 1500
+    fl = 4.0 * B * H * T * T * 64
+    for rnd in range(3):
+        _lib.check(m._lib.fw_bench_attention(h, B, H, T, 0, 50, C.byref(ms)))
+        print(f"round {rnd}: {ms.value * 1e3:.1f} us per launch, {fl / ms.value / 1e9:.0f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -204,7 +204,7 @@ def test_dec_linear_layernorm_folded_gelu(model, R, N, K):
 BIG_CFGS = (0, 1, 2)     # workgroup shapes of dec_gemm_big_kernel (dec_kernels.hip: launch_dec_gemm_big)
 
 
-@pytest.mark.parametrize("R", [80, 333, 1521, 1680])
+@pytest.mark.parametrize("R", [5, 80, 333, 1521, 1680])
 def test_dec_linear_big_bit_identical(model, R):
     """the GEMM-shaped decoder linear of merged runs (dec_gemm_big_kernel: 64 x 64 outputs per wave, fragments staged
     once per workgroup tile in LDS) must return EXACTLY the bits of the skinny kernel of solo runs at every large-v3
@@ -226,7 +226,8 @@ def test_dec_linear_big_bit_identical(model, R):
         ref = (_gelu(base) if act else base) + (r if use_res else 0.0)
         err = np.abs(a - ref).max() / max(1.0, np.abs(ref).max())
         assert err < 4e-3, (N, K, err)
-        for variant in (0,) + tuple(10 + c for c in BIG_CFGS):  # 0: what a decode step launches at this row count
+        # 0: what a decode step launches at this row count; 6 / 7: one tile / 2 x 2 tiles per workgroup
+        for variant in (0, 6, 7) + tuple(10 + c for c in BIG_CFGS):
             t, t_frag = _dec_linear(model, x, W, bias=b, ln=lnp, res=r, act=act, int8=variant)
             same = np.array_equal(a, t)
             print(f"big[{variant}] vs skinny {R}x{N}x{K} ln={ln} act={act}: identical={same}, "
