@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that refreshes the evidence set of a round (run from the repo root on the GPU box):
 #
-#   gpurun --timeout 1200 -- 'timeout 1100 bash profiles/collect.sh r02'
+#   gpurun --timeout 1200 -- 'timeout 1100 bash profiles/collect.sh r03'
 #
 # Writes under gpurun_out/<tag>/ and copies what is to be judged into profiles/<tag>_*:
 #   bench.json                  python bench.py (the bench line: roofline + cpu_baseline + secondary measurements)
@@ -13,15 +13,14 @@
 # Counter passes are separate runs with --pmc only (gpurun refuses --pmc combined with the trace domains).
 # The decode step runs eagerly under the profiler (FWAMD_NO_GRAPH=1): rocprofv3 7.2 crashes on replayed hipGraphs.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export FWAMD_BLOB_CACHE=/tmp/fwamd_blob
 Q="--no-cpu-baseline --no-profile-pass --no-secondary"
 cd "$R"
-timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-400 "$OUT/bench.json"
-cp "$OUT/bench.json" "$R/profiles/${TAG}_bench.json"
+# (the bench line itself is taken AFTER the counter passes — bench.py reads this round's FETCH_SIZE pass for `traffic`)
 cd /tmp; export TMPDIR=/tmp
 trace() {   # name, bench args...
   local name=$1; shift
@@ -42,9 +41,13 @@ pmc() {     # name, bench args ... -- counters...
   rm -rf "$OUT/prof_$name"
 }
 trace w1 --workers 1 --steps 2 --warmup 1
-trace w32 --steps 32 --warmup 1
+trace w32 --steps 64 --warmup 1
 pmc fetch --workers 1 --steps 2 --warmup 1 -- FETCH_SIZE
 pmc sq --workers 1 --steps 1 --warmup 1 -- SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
+cd "$R"
+cp "$OUT/pmc_fetch.json" "$R/profiles/${TAG}_pmc_fetch.json" 2>/dev/null
+timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-400 "$OUT/bench.json"
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2> "$OUT/bench_driver_cmd.err"; echo "driver-cmd bench rc=$?"; cut -c1-300 "$OUT/bench_driver_cmd.json"
 head -12 "$OUT/kernel_stats_w1.csv" | cut -c1-150
 head -8 "$OUT/kernel_stats_w32.csv" | cut -c1-150
 ls -la "$OUT"

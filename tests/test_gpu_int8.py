@@ -89,7 +89,9 @@ def test_gemm_int8_transposed_epilogue(kmodel, M, N, K):
 
 
 @pytest.mark.parametrize("R,N,K", [(80, 1280, 1280), (80, 5120, 1280), (80, 1280, 5120), (77, 3840, 1280),
-                                   (5, 128, 128), (333, 256, 512), (640, 1280, 1280)])
+                                   (5, 128, 128), (333, 256, 512), (640, 1280, 1280),
+                                   # merged runs: 4 x 4 tiles per workgroup from 1 024 rows on (ragged last row group)
+                                   (1029, 1280, 1280), (1100, 1280, 5120)])
 def test_dec_linear_int8_exact(kmodel, R, N, K):
     """the int8 decoder linear of a decode step (row quantiser writing fragment-major + v_mfma_i32_16x16x64_i8
     register-streaming GEMM) against the exact integer reference, at the large-v3 step shapes"""
