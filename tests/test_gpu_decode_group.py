@@ -134,3 +134,65 @@ def test_detect_language_and_align_through_a_worker():
     assert lang == lang1
     for a, b in zip(al, al1):
         assert a.alignments == b.alignments and a.text_token_probs == b.text_token_probs
+
+
+def test_merge_wait_zero_never_waits_and_knob_is_validated():
+    """fw_model_set_merge_wait(0, ...): the leader of a run takes what is queued at once — a call that arrives alone runs
+    alone even while other workers encode — and the result is the same bits either way"""
+    from faster_whisper_amd import _lib
+    cfg, model = _model("micro", 3)
+    lib = model._lib
+    h = model._replicas[0].handle
+    assert lib.fw_model_set_merge_wait(h, -2, 50) != 0 and lib.fw_model_set_merge_wait(h, 10, 0) != 0   # rejected
+    _lib.check(lib.fw_model_set_merge_wait(model._replicas[1].handle, 0, 90))    # through a worker: reaches the group
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True)
+    batch = _batches(1, 3)[0]
+    ref = model.generate(model.encode_pcm(batch), [prompt] * 3, **kw)
+    stop = threading.Event()
+
+    def keep_encoding():
+        while not stop.is_set():
+            model.encode_pcm(batch[:1])
+
+    bg = threading.Thread(target=keep_encoding)
+    bg.start()
+    try:
+        runs0 = model.decode_stats()["runs"]
+        got = model.generate(model.encode_pcm(batch), [prompt] * 3, **kw)
+        assert model.decode_stats()["runs"] == runs0 + 1
+    finally:
+        stop.set()
+        bg.join()
+    for a, b in zip(got, ref):
+        assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
+
+
+def test_free_order_does_not_matter():
+    """fw_model_free of the primary (weights + decode workspace) before its workers is deferred until the last worker is
+    gone: the workers keep working, nothing dangles"""
+    cfg, model = _model("micro", 3)
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    batch = _batches(1, 2)[0]
+    kw = dict(beam_size=2, max_length=len(prompt) + 6, return_scores=True)
+    ref = model.generate(model.encode_pcm(batch), [prompt] * 2, **kw)
+    reps = list(model._replicas)
+    reps[0].close()                                   # the primary first
+    model._replicas = reps[1:]                        # the workers still encode and decode (on the primary's workspace)
+    model._tls = threading.local()
+    got = model.generate(model.encode_pcm(batch), [prompt] * 2, **kw)
+    for a, b in zip(got, ref):
+        assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
+    for r in reps[1:]:
+        r.close()                                     # the last one takes the primary with it
+    model._replicas = []
+    cfg2, fresh = _model("micro", 1)
+    assert len(fresh.generate(fresh.encode_pcm(batch), [prompt] * 2, **kw)) == 2
+
+
+def test_row_capacity_is_checked_at_creation():
+    from faster_whisper_amd import Whisper, get_config, synthetic_weights
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=21)
+    with pytest.raises(ValueError):
+        Whisper("synthetic:micro", device="cuda", files={"config": cfg, "weights": w}, max_batch_size=200, max_beam_size=16)
