@@ -56,6 +56,9 @@ class GenResult:
     # log-probs along the greedy path.  beam search: per step, the gap between candidates K and K + 1 of
     # cum + logp (the pruning boundary)
     margins: List[float] = field(default_factory=list)
+    # teacher forcing (force_tokens, greedy): per step, log-prob of the best token minus log-prob of the FORCED token
+    # (0 where the forced token is the arg-max): how far every choice of a given sequence is from greedy-optimal
+    forced_gaps: List[float] = field(default_factory=list)
 
 
 @dataclass
@@ -460,7 +463,7 @@ class OracleWhisper:
 
     def _greedy(self, cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced, sample=None):
         c = self.cfg
-        gen, margins = [], []
+        gen, margins, gaps = [], [], []
         cum = np.float32(0.0)
         step = 0
         ended = False
@@ -478,6 +481,7 @@ class OracleWhisper:
             tok = int(order[0])
             if forced is not None and step < len(forced):
                 tok = int(forced[step])
+                gaps.append(float(lp[order[0]] - lp[tok]))
             cum = np.float32(cum + lp[tok])
             step += 1
             if tok == c.eot:
@@ -489,7 +493,7 @@ class OracleWhisper:
             h = self.decoder_step(torch.tensor([tok]), P - 1 + step, cache, ckv1)
             logits = self.logits(h).numpy()
         score = _hyp(cum, gen, lp_pow)[0]
-        return GenResult([gen], [float(score)], no_speech, margins)
+        return GenResult([gen], [float(score)], no_speech, margins, gaps)
 
     # ------------------------------------------------------------------ detect_language
     def detect_language(self, enc: np.ndarray):

@@ -93,6 +93,20 @@ def forced_score(oracle, enc_np_b, prompt, ids, kw):
     return r.scores[0]
 
 
+def greedy_gaps(oracle, enc_np_b, prompt, ids, kw):
+    """the oracle teacher-forced along a GIVEN greedy sequence: per step, log-prob of the oracle's best token minus the
+    log-prob of the sequence's token (0 where they agree).  A greedy engine whose every choice is within the numerical
+    noise of the oracle's arg-max has all gaps below that noise — a statement about EVERY step of the engine's output,
+    which a comparison of id prefixes (it ends at the first numerically tied step) cannot make."""
+    from oracle.whisper import max_new_tokens
+    budget = max_new_tokens(kw.get("max_length", 448), len(prompt))
+    forced = list(ids) + ([oracle.cfg.eot] if len(ids) < budget else [])
+    k2 = {k: v for k, v in kw.items() if k not in ("beam_size", "patience", "num_hypotheses")}
+    r = oracle.generate(enc_np_b[None] if enc_np_b.ndim == 2 else enc_np_b, [list(prompt)], beam_size=1,
+                        force_tokens=[forced], **k2)[0]
+    return r.forced_gaps
+
+
 def check_hypothesis(oracle, enc_np_b, prompt, got, ref, kw, tol=1e-3, gap=2e-2, what="", search=True, boundary=0.0):
     """Parity criterion for one chunk of a beam-search (or greedy) result — never skipped, never "most of the time":
       1. the engine's reported score equals the ORACLE's score of the engine's own token sequence within `tol`
