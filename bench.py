@@ -159,6 +159,9 @@ def parse_args(argv=None):
                          "weights, shared decode group).  The merged decode run grows with the batches in flight "
                          "and every decoder weight is streamed once per run: measured 6: 2 221x, 8: 2 405x, 12: 2 523x, "
                          "16: 2 595x, 20: 2 740x, 24: 2 765x, 32: 2 834x (decode workspace clamped to 336 chunks by HBM)")
+    ap.add_argument("--decode-lanes", type=int, default=2, choices=[1, 2],
+                    help="decode runs in flight per GPU (2: the product's default; 1: one run at a time, used for the kernel "
+                         "traces in profiles/ so that kernel durations are not stretched by the other lane's kernels)")
     ap.add_argument("--merge-fill", type=int, default=None,
                     help="share (percent) of a decode run's chunk capacity the leader of a run waits for (backend default 90)")
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
@@ -205,6 +208,9 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     model, weights = (backend_factory or build_backend)(args, cfg, rank, world, local_rank)
     load_s = time.time() - t0
 
+    lanes = getattr(args, "decode_lanes", 2)
+    if lanes != 2 and hasattr(model, "set_decode_lanes"):
+        model.set_decode_lanes(lanes)
     chunks = synth_chunks(args.batch, seed=1000 + rank)
     staged = model.stage_pcm(chunks)
     prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
@@ -296,7 +302,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                             "contract); `pipeline` is the SURVEY section 8d wall (ndarray in host memory -> last Segment)",
         "config": {"workload": f"{args.model} {args.compute_type} BatchedInferencePipeline hot path: {args.batch} x 30 s "
                                f"chunks/step, beam_size={args.beam}, {L} new tokens/chunk (fixed), PCM resident in HBM",
-                   "global_batch": args.batch * world, "new_tokens": L, "workers_per_gpu": W,
+                   "global_batch": args.batch * world, "new_tokens": L, "workers_per_gpu": W, "decode_lanes": lanes,
                    "decode_group": {"capacity_chunks": stats1["decode_batch"], "decode_runs": runs,
                                     "chunks_per_run": round((stats1["chunks"] - stats0["chunks"]) / runs, 1),
                                     "largest_run_chunks": stats1["max_run_chunks"]},
@@ -329,11 +335,17 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         # ---- roofline of the dominant kernel family: one profiled round of the same workload (HIP events on the
         #      engine's streams; the decode step runs eagerly instead of as a graph replay while profiling) ----
         if not args.no_profile_pass:
+            # ONE decode run at a time while profiling: with two lanes a kernel's event-to-event time would include the
+            # other lane's kernels running beside it; the roofline is a statement about the kernel
+            if hasattr(model, "set_decode_lanes"):
+                model.set_decode_lanes(1)
             model.profile(True, replica=None)
             run_steps(W, gather=False)
             model.synchronize()
             rep = model.profile_report(replica=None)
             model.profile(False, replica=None)
+            if hasattr(model, "set_decode_lanes"):
+                model.set_decode_lanes(lanes)
             for v in rep.values():             # per batch-step
                 for f in ("ms", "bytes", "flops"):
                     v[f] /= W
@@ -366,7 +378,9 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             roof["kernel_ms_per_step"] = round(dom["ms"], 3)
             roof["launch_groups_in_round"] = dom["launches"]
             roof["timing"] = (f"HIP events around every launch on the engine's streams, one round of {W} batches with "
-                              "all workers active (as in the timed region), divided by the batches")
+                              "all workers active, divided by the batches; the profiled round decodes ONE run at a time "
+                              f"(the timed region: {lanes} decode lane(s) — with two, kernels of two runs share the chip "
+                              "and a kernel's wall time is no longer its own)")
             parts = [v for k, v in rep.items() if k.startswith("dec_gemm_")]
             others = {}
             if parts:

@@ -307,6 +307,11 @@ class Whisper:
     def config(self) -> WhisperConfig:
         return self._cfg
 
+    def set_decode_lanes(self, lanes: int):
+        """decode runs a device's group may have in flight (fwamd.h: fw_model_set_decode_lanes): 2, or 1 for per-kernel timing"""
+        for i in sorted({self._primary_of(r) for r in range(len(self._replicas))}):
+            _lib.check(self._lib.fw_model_set_decode_lanes(self._replicas[i].handle, int(lanes)))
+
     def synchronize(self):
         """block until everything queued on the encoder and decode streams of every worker has finished"""
         for r in self._replicas:

@@ -402,6 +402,7 @@ struct GenRequest {
   int with_ts = 1, sot_pos = -1;   // from the prompt: no <|notimestamps|> -> timestamp rules; position of <sot>
   int rc = FW_OK;
   std::string err;
+  bool taken = false;   // part of a run that is being decoded (its caller waits for `done`, it must not lead another run)
   bool done = false;
 };
 
@@ -708,24 +709,24 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   std::unique_lock<std::mutex> lk(grp.mu);
   grp.queue.push_back(&req);
   grp.last_arrival = std::chrono::steady_clock::now();
+  const int n_lanes = dm->lane1 ? 2 : 1;
   while (!req.done) {
-    if (grp.leader_active) {
+    if (req.taken || grp.gathering || grp.active_runs >= std::min(n_lanes, grp.lanes_enabled.load())) {
       grp.cv.wait(lk);
       continue;
     }
     // lead the next run: wait for the requests of workers that are still encoding (each arrives within one
-    // encoder pass) unless half of the workspace is already claimed, then take every queued request that can share
+    // encoder pass) unless most of a run's capacity is already claimed, then take every queued request that can share
     // a run with the oldest one.  The wait trades this caller's latency for rows per run; it is bounded by the
     // merge-wait knob (fw_model_set_merge_wait: default one measured encoder pass after the last arrival, at most
-    // 120 ms; 0 = never) and skipped when no member encode is in flight.
-    grp.leader_active = true;
+    // 120 ms; 0 = never) and skipped when no member encode is in flight.  One caller gathers at a time; with two lanes
+    // the next one starts gathering as soon as this one has taken its requests and gone off to run them.
+    grp.gathering = true;
     const int cap = std::max(dm->decode_batch, dm->max_batch);
     int wait_ms = grp.merge_wait_ms.load();
     if (wait_ms < 0) wait_ms = std::min(120, std::max(5, (grp.enc_pass_us.load() * 5 / 4 + 999) / 1000));
     const int fill_pct = grp.merge_fill_pct.load();
     if (cap > dm->max_batch && wait_ms > 0 && !grp.queue.front()->sampling) {
-      // (waiting for a quarter, a half or the whole workspace measured the same throughput within 1 %:
-      //  profiles/r02_mid_*; one half keeps two runs alternating, so encoders and result handling overlap a run)
       for (;;) {
         int queued = 0;
         for (const GenRequest* r : grp.queue) queued += r->B;
@@ -748,12 +749,18 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
       GenRequest* r = *it;
       if (r == first || (mergeable(*first, *r) && chunks + r->B <= run_cap)) {
         batch.push_back(r);
+        r->taken = true;
         chunks += r->B;
         it = grp.queue.erase(it);
       } else {
         ++it;
       }
     }
+    const int lane = (n_lanes == 2 && grp.lane_busy[0]) ? 1 : 0;
+    grp.lane_busy[lane] = true;
+    grp.active_runs += 1;
+    grp.gathering = false;
+    grp.cv.notify_all();                    // (the next leader may gather while this run decodes)
     lk.unlock();
     grp.n_runs.fetch_add(1);
     grp.n_requests.fetch_add((int64_t)batch.size());
@@ -761,13 +768,15 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     if (chunks > grp.max_run_chunks.load()) grp.max_run_chunks.store(chunks);
     int rc;
     {
-      std::lock_guard<std::mutex> dl(dm->dec_mu);
-      rc = generate_run(dm, batch);
+      Model* lm = lane ? dm->lane1 : dm;    // the lane's model: own workspace, own stream, same weights
+      std::lock_guard<std::mutex> dl(lm->dec_mu);
+      rc = generate_run(lm, batch);
     }
     const std::string err = rc ? fw_last_error() : "";
     lk.lock();
     for (GenRequest* r : batch) { r->rc = rc; r->err = err; r->done = true; }
-    grp.leader_active = false;
+    grp.lane_busy[lane] = false;
+    grp.active_runs -= 1;
     grp.cv.notify_all();
   }
   lk.unlock();

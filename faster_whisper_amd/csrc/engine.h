@@ -104,7 +104,10 @@ struct DecodeGroup {
   std::mutex mu;
   std::condition_variable cv;
   std::deque<GenRequest*> queue;
-  bool leader_active = false;
+  bool gathering = false;         // a caller is collecting the requests of the next run (one at a time)
+  int active_runs = 0;            // runs in flight (<= lanes of the group)
+  bool lane_busy[2] = {false, false};
+  std::atomic<int> lanes_enabled{2};   // fw_model_set_decode_lanes: runs allowed in flight (1 or 2)
   std::atomic<int> encoding{0};   // member encodes in flight: requests that are about to arrive
   std::chrono::steady_clock::time_point last_arrival{};   // when the newest request was queued
   std::mutex enc_mu;              // one encoder pass at a time per device
@@ -167,6 +170,12 @@ struct Model {
   // chunks, run on dec_stream under dec_mu) or has joined another model of the same device (decoder != null).
   GenWorkspace* gen = nullptr;
   Model* decoder = nullptr;
+  // Second decode LANE of a decode group (fw_model_set_decode_batch with room for >= 4 encoder batches): an internal,
+  // decoder-only model on the same weight blob with a workspace and a stream of its own, so that TWO decode runs of the
+  // group are in flight at once — the cross-attention stream of one (HBM-bound) beside the linears of the other:
+  // measured +8 % (profiles/r03_two_groups_probe.txt).  Owned by the primary; never visible through the C ABI.
+  Model* lane1 = nullptr;
+  bool is_lane = false;
   int decode_batch = 0;
   int decode_self_ctx = 0;   // self-attention cache positions per row at full row capacity (0 = the text context)
   int dependents = 0;        // live models that use this one's weight blob or decode workspace (g_models_mu)

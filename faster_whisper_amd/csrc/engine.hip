@@ -648,7 +648,7 @@ static int alloc_workspaces(Model* m) {
 }
 
 static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned, int device, int max_batch,
-                           int max_beam, fw_model** out) {
+                           int max_beam, fw_model** out, bool decoder_lane = false) {
   FW_CHECK_ARG(max_batch >= 1 && max_batch <= 256, "max_batch must be in [1,256], got %d", max_batch);
   FW_CHECK_ARG(max_beam >= 1 && max_beam <= 16, "max_beam must be in [1,16], got %d", max_beam);
   FW_CHECK_ARG(max_batch * max_beam <= 2048, "max_batch * max_beam must be <= 2048 decoder rows, got %d", max_batch * max_beam);
@@ -695,8 +695,11 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
     return fail(FW_ENODEV);
   }
   if ((rc = bind_weights(m))) return fail(rc);
-  if ((rc = setup_logmel_consts(m))) return fail(rc);
-  if ((rc = alloc_workspaces(m))) return fail(rc);
+  m->is_lane = decoder_lane;
+  if (!decoder_lane) {   // (a decode lane has no front end and no encoder: weights, a stream, a decode workspace)
+    if ((rc = setup_logmel_consts(m))) return fail(rc);
+    if ((rc = alloc_workspaces(m))) return fail(rc);
+  }
   m->decode_batch = max_batch;   // the decode workspace itself is created on first use (decoder.hip)
   he = hipDeviceSynchronize();
   if (he != hipSuccess) {
@@ -707,10 +710,10 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
     // a model on a borrowed blob (fw_model_create_from_blob_dev on fw_model_blob's pointer) keeps the owner alive:
     // fw_model_free(owner) is deferred until its last dependent is gone
     std::lock_guard<std::mutex> lk(g_models_mu_ref());
-    if (!owned)
+    if (!owned && !decoder_lane)
       for (Model* o : g_live_models_ref())
         if (o->blob == m->blob && o->blob_owned) { m->blob_owner = o; o->dependents += 1; break; }
-    g_live_models_ref().push_back(m);
+    if (!decoder_lane) g_live_models_ref().push_back(m);   // (a lane lives and dies with its primary)
   }
   m->self = fm;
   *out = fm;
@@ -1053,6 +1056,10 @@ void fw_model_free(fw_model* fm) {
     release[1] = m->decoder;
   }
   (void)hipSetDevice(m->device);
+  if (m->lane1) {
+    fw_model_free(static_cast<fw_model*>(m->lane1->self));
+    m->lane1 = nullptr;
+  }
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   if (m->dec_stream) (void)hipStreamSynchronize(m->dec_stream);
   gen_workspace_free(m);
@@ -1100,6 +1107,9 @@ int32_t fw_model_info(const fw_model* fm, fw_config* cfg_out, int32_t* compute_t
   return FW_OK;
 }
 
+// rows of the largest decode run of a group (decoder.hip: DEC_RUN_MAX_ROWS)
+#define DEC_GROUP_RUN_ROWS 1600
+
 int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   FW_CHECK_ARG(fm, "null model");
   Model* m = &fm->impl;
@@ -1110,32 +1120,60 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   // Whole encoder batches, at least one, at most 2048 rows, in 70 % of the free HBM.  The cross-attention cache is
   // fixed per chunk; the self-attention cache is rows x positions and a RUN lays it out for its own max_length
   // (decoder.hip), so when the requested chunks do not fit with the whole text context per row, the positions per
-  // row are lowered first (down to 128: a run that asks for more then simply holds fewer rows) and only then the
+  // row are lowered first (down to 160: a run that asks for more then simply holds fewer rows) and only then the
   // chunk count.
+  // Two lanes (two concurrent decode runs, engine.h: lane1) when the group is asked to hold at least four encoder
+  // batches; every lane is sized for the largest run there can be: the requested chunks, at most DEC_GROUP_RUN_ROWS
+  // rows (decoder.hip caps runs there).  The budget below is for all lanes together.
   int want = std::max(decode_batch, m->max_batch) / m->max_batch * m->max_batch;
-  while (want > m->max_batch && (int64_t)want * m->max_beam > 2048) want -= m->max_batch;
+  const int n_lanes = want >= 4 * m->max_batch ? 2 : 1;
+  while (want > m->max_batch && (int64_t)want * m->max_beam > (n_lanes == 2 ? DEC_GROUP_RUN_ROWS : 2048)) want -= m->max_batch;
   size_t free_b = 0, total_b = 0;
   FW_HIP(hipMemGetInfo(&free_b, &total_b));
   if (m->gen) free_b += (size_t)gen_workspace_bytes(m, m->decode_batch, m->decode_self_ctx);
+  if (m->lane1 && m->lane1->gen) free_b += (size_t)gen_workspace_bytes(m->lane1, m->lane1->decode_batch, m->lane1->decode_self_ctx);
   const int64_t budget = (int64_t)(0.7 * (double)free_b);
   const int NT = m->cfg.n_text_ctx;
-  const int ctx_steps[] = {NT, 320, 224, 160, 128};
+  const int ctx_steps[] = {NT, 320, 224, 160};
   int self_ctx = NT;
   for (;;) {
     bool fits = false;
     for (int cs : ctx_steps) {
       if (cs > NT) continue;
-      if (gen_workspace_bytes(m, want, cs) <= budget) { self_ctx = cs; fits = true; break; }
+      if (n_lanes * gen_workspace_bytes(m, want, cs) <= budget) { self_ctx = cs; fits = true; break; }
     }
     if (fits || want <= m->max_batch) break;
     want -= m->max_batch;
   }
-  if (m->gen && want == m->decode_batch && self_ctx == m->decode_self_ctx) return FW_OK;
+  const bool lanes_ok = (n_lanes == 2) == (m->lane1 != nullptr);
+  if (m->gen && lanes_ok && want == m->decode_batch && self_ctx == m->decode_self_ctx) return FW_OK;
   if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
   gen_workspace_free(m);
+  if (m->lane1) {
+    fw_model_free(static_cast<fw_model*>(m->lane1->self));
+    m->lane1 = nullptr;
+  }
   m->decode_batch = want;
   m->decode_self_ctx = self_ctx;
-  return gen_workspace_ensure(m);
+  int rc = gen_workspace_ensure(m);
+  if (rc) return rc;
+  if (n_lanes == 2) {
+    fw_model* l = nullptr;
+    if ((rc = model_from_blob(m->blob, m->blob_bytes, false, m->device, m->max_batch, m->max_beam, &l, true))) return rc;
+    l->impl.decode_batch = want;
+    l->impl.decode_self_ctx = self_ctx;
+    l->impl.prof_on = m->prof_on;
+    if ((rc = gen_workspace_ensure(&l->impl))) { fw_model_free(l); return rc; }
+    m->lane1 = &l->impl;
+  }
+  return FW_OK;
+}
+
+int32_t fw_model_set_decode_lanes(fw_model* fm, int32_t lanes) {
+  FW_CHECK_ARG(fm, "null model");
+  FW_CHECK_ARG(lanes == 1 || lanes == 2, "decode lanes: 1 or 2");
+  decoder_of(&fm->impl)->grp.lanes_enabled.store(lanes);
+  return FW_OK;
 }
 
 int32_t fw_model_set_merge_wait(fw_model* fm, int32_t wait_ms, int32_t fill_percent) {
@@ -1412,20 +1450,39 @@ void fw_tensor_free(fw_tensor* t) {
 }
 
 // ---------------------------------------------------------------- measurement hooks
-void fw_prof_enable(fw_model* fm, int32_t on) { if (fm) fm->impl.prof_on = on != 0; }
+void fw_prof_enable(fw_model* fm, int32_t on) {
+  if (!fm) return;
+  fm->impl.prof_on = on != 0;
+  if (fm->impl.lane1) fm->impl.lane1->prof_on = on != 0;
+}
 void fw_prof_reset(fw_model* fm) {
   if (!fm) return;
   prof_collect(&fm->impl);
-  std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
-  for (auto& p : fm->impl.prof) p = ProfAcc();
+  {
+    std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
+    for (auto& p : fm->impl.prof) p = ProfAcc();
+  }
+  if (Model* l = fm->impl.lane1) {
+    prof_collect(l);
+    std::lock_guard<std::mutex> lk(l->prof_mu);
+    for (auto& p : l->prof) p = ProfAcc();
+  }
 }
 int32_t fw_prof_count(void) { return PF_COUNT; }
 const char* fw_prof_name(int32_t i) { return (i >= 0 && i < PF_COUNT) ? kProfNames[i] : ""; }
 int32_t fw_prof_get(fw_model* fm, int32_t i, double* ms, int64_t* launches, double* flops, double* bytes) {
   FW_CHECK_ARG(fm && i >= 0 && i < PF_COUNT, "bad profile index");
   prof_collect(&fm->impl);
-  std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
-  const ProfAcc& p = fm->impl.prof[i];
+  ProfAcc p;
+  {
+    std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
+    p = fm->impl.prof[i];
+  }
+  if (Model* l = fm->impl.lane1) {   // the second decode lane of the group reports through its primary
+    prof_collect(l);
+    std::lock_guard<std::mutex> lk(l->prof_mu);
+    p.ms += l->prof[i].ms; p.launches += l->prof[i].launches; p.flops += l->prof[i].flops; p.bytes += l->prof[i].bytes;
+  }
   if (ms) *ms = p.ms;
   if (launches) *launches = p.launches;
   if (flops) *flops = p.flops;
@@ -1437,6 +1494,7 @@ int32_t fw_synchronize(fw_model* fm) {
   FW_HIP(hipSetDevice(fm->impl.device));
   FW_HIP(hipStreamSynchronize(fm->impl.stream));
   if (fm->impl.dec_stream) FW_HIP(hipStreamSynchronize(fm->impl.dec_stream));
+  if (fm->impl.lane1 && fm->impl.lane1->dec_stream) FW_HIP(hipStreamSynchronize(fm->impl.lane1->dec_stream));
   return FW_OK;
 }
 int32_t fw_dev_alloc(fw_model* fm, int64_t bytes, void** out_dev) {

@@ -158,7 +158,9 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
  *   fw_model_set_decode_batch(primary, n_workers * max_batch)  sizes the primary's decode workspace for that many
  *       chunks (rounded down to whole encoder batches, 2048 rows and what fits in HBM; fw_model_decode_batch reads it
  *       back).  The self-attention cache is rows x positions and every run lays it out for its own max_length, so a
- *       run of calls with a short max_length holds more chunks than one that asks for the whole text context;
+ *       run of calls with a short max_length holds more chunks than one that asks for the whole text context.  From
+ *       four encoder batches on, the group decodes on TWO lanes (two workspaces, two streams, the budget covers both):
+ *       two decode runs are in flight at once, the HBM-bound cross-attention of one beside the linears of the other;
  *   fw_model_join_decoder(worker, primary)  frees the worker's own decode workspace and routes its fw_generate /
  *       fw_detect_language / fw_align calls to the primary's.
  * fw_generate calls with identical options that arrive from different host threads while a decode run is in
@@ -174,6 +176,9 @@ int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
  * amortise the decoder weights and launches over more rows and take the GEMM-shaped decoder linears; measured 2 917x
  * at 50, 2 965x at 75, 2 975x at 95; smaller = lower latency).  It never waits when no member encode is in flight. */
 int32_t fw_model_set_merge_wait(fw_model* m, int32_t wait_ms, int32_t fill_percent);
+/* Decode runs the group may have in flight: 2 (default, when the group has two lanes) or 1 (one run at a time: every
+ * kernel of a run has the chip to itself — what per-kernel timing wants; takes effect with the next run). */
+int32_t fw_model_set_decode_lanes(fw_model* m, int32_t lanes);
 /* counters of the decode group `m` belongs to: decode runs, fw_generate calls served, chunks decoded, chunks of
  * the largest run (any pointer may be NULL) */
 int32_t fw_model_decode_stats(const fw_model* m, int64_t* runs, int64_t* requests, int64_t* chunks,

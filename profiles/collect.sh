@@ -18,7 +18,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export FWAMD_BLOB_CACHE=/tmp/fwamd_blob
-Q="--no-cpu-baseline --no-profile-pass --no-secondary"
+# kernel traces and counter passes: ONE decode run at a time (--decode-lanes 1), so that a kernel's duration is its own
+Q="--no-cpu-baseline --no-profile-pass --no-secondary --decode-lanes 1"
 cd "$R"
 # (the bench line itself is taken AFTER the counter passes — bench.py reads this round's FETCH_SIZE pass for `traffic`)
 cd /tmp; export TMPDIR=/tmp

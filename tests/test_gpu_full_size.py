@@ -244,10 +244,11 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
         except Exception as ex:   # noqa: BLE001
             errs.append(ex)
 
-    def blocker():
+    def blocker(extra):
+        # (a long run with options of its own: not mergeable with the callers, nor with the other blocker)
         try:
-            model.generate(encs[0], [prompt] * len(batches[0]), **dict(kw, max_length=len(prompt) + 4 * steps,
-                                                                      min_new_tokens=4 * steps))
+            model.generate(encs[extra], [prompt] * len(batches[extra]),
+                           **dict(kw, max_length=len(prompt) + 4 * steps + extra, min_new_tokens=4 * steps))
         except Exception as ex:   # noqa: BLE001
             errs.append(ex)
 
@@ -255,18 +256,20 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
     for t in ts:
         t.start()
     encoded.wait()                                    # every worker holds its encoder output
-    bt = threading.Thread(target=blocker)
-    bt.start()
+    # the group decodes on two lanes (two runs in flight): both are kept busy, so that every caller queues up
+    bts = [threading.Thread(target=blocker, args=(x,)) for x in (0, 1)]
+    for bt in bts:
+        bt.start()
     t_end = time.time() + 60
-    while model.decode_stats()["runs"] == st0["runs"] and time.time() < t_end:
-        time.sleep(0.001)                             # the blocker's run has started
+    while model.decode_stats()["runs"] < st0["runs"] + 2 and time.time() < t_end:
+        time.sleep(0.001)                             # both blockers' runs have started
     go.set()
-    for t in ts + [bt]:
+    for t in ts + bts:
         t.join()
     assert not errs, errs
     st = model.decode_stats()
     n_chunks = sum(len(b) for b in batches)
-    print(f"{tag} {workers} concurrent calls ({n_chunks} chunks) -> {st['runs'] - st0['runs'] - 1} decode run(s), "
+    print(f"{tag} {workers} concurrent calls ({n_chunks} chunks) -> {st['runs'] - st0['runs'] - 2} decode run(s), "
           f"largest run {st['max_run_chunks']} chunks = {5 * st['max_run_chunks']} rows")
     assert st["max_run_chunks"] == n_chunks           # ONE run carried every caller
     for i in range(workers):
