@@ -196,3 +196,29 @@ def test_row_capacity_is_checked_at_creation():
     w = synthetic_weights(cfg, seed=21)
     with pytest.raises(ValueError):
         Whisper("synthetic:micro", device="cuda", files={"config": cfg, "weights": w}, max_batch_size=200, max_beam_size=16)
+
+
+def test_decode_lanes_switch():
+    """fw_model_set_decode_lanes: one run at a time or two — same kernels, same weights, same results"""
+    cfg, model = _model("micro", 4)                   # 12 chunks >= 4 encoder batches: the group has two lanes
+    lib = model._lib
+    assert lib.fw_model_set_decode_lanes(model._replicas[0].handle, 3) != 0       # rejected
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True)
+    batches = _batches(4, 3)
+    ref = [model.generate(model.encode_pcm(b), [prompt] * 3, **kw) for b in batches]
+    for lanes in (1, 2):
+        model.set_decode_lanes(lanes)
+        out = [None] * 4
+
+        def work(i):
+            out[i] = model.generate(model.encode_pcm(batches[i]), [prompt] * 3, **kw)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i in range(4):
+            for a, b in zip(out[i], ref[i]):
+                assert a.sequences_ids == b.sequences_ids and a.scores == b.scores, (lanes, i)
