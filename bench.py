@@ -30,6 +30,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -91,21 +92,33 @@ def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0, shard=
         t0 = time.perf_counter()
         segments, _ = pipe.transcribe(audio, **kw)
         n_seg = n_tok = n_words = 0
+        digest = 0
         for s in segments:
             n_seg += 1
             n_tok += len(s.tokens)
             n_words += len(s.words or ())
+            # order-sensitive checksum of what was yielded (ids, avg_logprob, no_speech_prob): a sharded run and a serial
+            # run of the same recording must agree on it
+            digest = zlib.crc32(np.asarray(s.tokens, dtype=np.int32).tobytes()
+                                + np.asarray([s.avg_logprob, s.no_speech_prob], dtype=np.float64).tobytes(), digest)
         if sync:
             sync()
         dt = time.perf_counter() - t0
         out = {"value": round(30.0 * n_chunks / dt, 2), "unit": "audio-seconds per wall-second",
-               "audio_s": 30.0 * n_chunks, "wall_s": round(dt, 3), "segments": n_seg, "tokens": n_tok,
+               "audio_s": 30.0 * n_chunks, "wall_s": round(dt, 3), "segments": n_seg, "tokens": n_tok, "digest": digest,
                "what": "BatchedInferencePipeline.transcribe, ndarray in host memory -> last Segment"}
         if word_timestamps:
             out["words"] = n_words
         return out
     except Exception as e:   # a secondary number must never take the bench line down
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+def _multi(world):
+    """the N > 1 control flow; FWAMD_DIST_AT_WORLD_1=1 takes it with ONE rank (RCCL communicator, blob broadcast, result
+    gather, MAX over ranks, sharded recording) — the way a 1-GPU box executes the nccl branch
+    (tests/test_gpu_rccl_world1.py)"""
+    return world > 1 or os.environ.get("FWAMD_DIST_AT_WORLD_1") == "1"
 
 
 def build_backend(args, cfg, rank, world, local_rank):
@@ -118,7 +131,7 @@ def build_backend(args, cfg, rank, world, local_rank):
     if getattr(args, "merge_fill", None) is not None:
         common["merge_fill_percent"] = args.merge_fill
     weights = None
-    if world > 1:
+    if _multi(world):
         blob = None
         if rank == 0:
             weights = synthetic_weights(cfg, seed=1234)
@@ -188,7 +201,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     on_gpu = dist_backend in (None, "nccl")
-    if world > 1:
+    multi = _multi(world)
+    if multi:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -227,7 +241,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         return model.generate(enc, [prompt] * args.batch, **gen_kw(n))
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         model.synchronize()
 
@@ -250,7 +264,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         outs = []
         for f in futs:                   # results come back in submission order = chunk order
             r = f.result()
-            if world > 1 and gather:
+            if multi and gather:
                 gather_results(r, n_tok, rank, world, local_rank)
             outs.append(r)
         return outs
@@ -264,7 +278,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         barrier()
         dt = time.perf_counter() - t1
         last["res"] = res
-        if world > 1:
+        if multi:
             import torch
             tt = torch.tensor([dt], device=f"cuda:{local_rank}" if on_gpu else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -326,7 +340,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         dt2 = timed(n2, 224)
         out["cap_case"] = {"new_tokens": 224, "value": round(30.0 * args.batch * n2 * world / dt2, 2),
                            "unit": "audio-seconds per wall-second", "steps": n2}
-        if world > 1:
+        if multi:
             out["sharded_recording"] = dict(
                 pipeline_rtf(model, cfg, args.sharded_chunks, args.batch, args.beam, L, shard=True, sync=barrier),
                 scaling="strong", n_gpus=world)
@@ -411,19 +425,19 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                 elif v["bytes"] > 0:
                     fam[k] = {"GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
             out["families_rate"] = fam
-        if secondary and world == 1:
+        if secondary and not multi:
             out["pipeline"] = pipeline_rtf(model, cfg, args.pipeline_chunks, args.batch, args.beam, L,
                                            word_timestamps=args.word_timestamps)
             out["single_utterance"] = single_utterance(model, cfg, chunks[0], prompt, gen_kw(L), L)
             out["one_batch_at_a_time"] = one_batch(model, staged, chunks, prompt, gen_kw(L), L, args.batch)
         # ---- CPU baseline: the oracle (torch fp32 port) on a bounded sample of the same workload ----
         # (reported at N = 1 only: at N > 1 the other ranks would idle at the final barrier while it runs)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks[0], prompt, args.beam, L, gen_kw(L))
         print(json.dumps(out), flush=True)
     model.free_staged(staged)
     pool.shutdown()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return out

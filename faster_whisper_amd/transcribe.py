@@ -976,7 +976,7 @@ class BatchedInferencePipeline:
             enc, outs = self.generate_segment_batched(feats, tokenizer, options,
                                                       audio_chunks=chunks if fused_features else None)
             local = aligned = None
-            if world == 1 or options.word_timestamps:
+            if not shard or options.word_timestamps:
                 local, sizes = self._split_outputs(outs, tokenizer, chunks_metadata[i0:i1])
                 if options.word_timestamps:
                     # the chunk-local half of the word timing runs where the encoder output lives
@@ -1013,7 +1013,7 @@ class BatchedInferencePipeline:
                                   no_speech_prob=seg["no_speech_prob"], compression_ratio=seg["compression_ratio"],
                                   temperature=options.temperatures[0])
 
-        if world == 1:
+        if not shard:
             # single process: segments are yielded as soon as their batch is decoded
             for _, results, aligned in batches(0, n):
                 if options.word_timestamps:
@@ -1021,7 +1021,8 @@ class BatchedInferencePipeline:
                 yield from emit(results)
             self.last_speech_timestamp = 0.0
             return
-        # sharded: every rank decodes its contiguous block of the chunk list (no collective in the data path), then
+        # sharded (a job of ONE rank takes this path too: same result, and the way a 1-GPU box executes the RCCL
+        # gather): every rank decodes its contiguous block of the chunk list (no collective in the data path), then
         # ONE gather brings the fixed-size result records — and the chunk-local word alignments — to rank 0, in
         # rank order = the serial order
         bounds = partition(n, world)
