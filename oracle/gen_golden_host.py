@@ -154,9 +154,56 @@ def run_units(fw, cfg, hf_tok):
     return out
 
 
+def api_surface(fw):
+    """the reference's public call surface for this path: parameter names, order and defaults of the entry points, the
+    field lists of the result dataclasses, the package exports (faster_whisper/__init__.py, transcribe.py:66-108,
+    :589-698, :720-780, :254-330; vad.py:14-43; audio.py:20-47)"""
+    import inspect
+    from faster_whisper import audio as ref_audio
+    from faster_whisper import transcribe as ref_tr
+    from faster_whisper import vad as ref_vad
+
+    def sig(f):
+        out = []
+        for name, p in inspect.signature(f).parameters.items():
+            if name == "self":
+                continue
+            d = None if p.default is inspect.Parameter.empty else repr(p.default)
+            out.append([name, {"VAR_KEYWORD": "**", "VAR_POSITIONAL": "*"}.get(p.kind.name, ""), d])
+        return out
+
+    def fields(c):
+        return [f.name for f in dataclasses.fields(c)]
+    return {
+        "exports": sorted(fw.__all__),
+        "signatures": {
+            "WhisperModel.__init__": sig(ref_tr.WhisperModel.__init__),
+            "WhisperModel.transcribe": sig(ref_tr.WhisperModel.transcribe),
+            "WhisperModel.detect_language": sig(ref_tr.WhisperModel.detect_language),
+            "BatchedInferencePipeline.__init__": sig(ref_tr.BatchedInferencePipeline.__init__),
+            "BatchedInferencePipeline.transcribe": sig(ref_tr.BatchedInferencePipeline.transcribe),
+            "decode_audio": sig(ref_audio.decode_audio),
+            "pad_or_trim": sig(ref_audio.pad_or_trim),
+            "get_speech_timestamps": sig(ref_vad.get_speech_timestamps),
+            "collect_chunks": sig(ref_vad.collect_chunks),
+        },
+        "dataclasses": {
+            "Word": fields(ref_tr.Word), "Segment": fields(ref_tr.Segment),
+            "TranscriptionOptions": fields(ref_tr.TranscriptionOptions),
+            "TranscriptionInfo": fields(ref_tr.TranscriptionInfo), "VadOptions": fields(ref_vad.VadOptions),
+        },
+        "vad_defaults": dataclasses.asdict(ref_vad.VadOptions()),
+    }
+
+
 def main():
     install_stubs()
     import faster_whisper as fw
+    if "--api-only" in sys.argv:
+        with open(os.path.join(OUT, "host_api.json"), "w") as f:
+            json.dump(api_surface(fw), f, indent=1)
+        print("wrote host_api.json")
+        return
     import faster_whisper.feature_extractor  # noqa: F401
     import faster_whisper.tokenizer as ref_tok
     from faster_whisper_amd import get_config
@@ -170,7 +217,9 @@ def main():
         json.dump(run_scenarios(fw, cfg, hf_tok), f, indent=0, ensure_ascii=False)
     with open(os.path.join(OUT, "host_units.json"), "w") as f:
         json.dump(run_units(fw, cfg, hf_tok), f, indent=0, ensure_ascii=False)
-    print("wrote host_scenarios.json, host_units.json")
+    with open(os.path.join(OUT, "host_api.json"), "w") as f:
+        json.dump(api_surface(fw), f, indent=1)
+    print("wrote host_scenarios.json, host_units.json, host_api.json")
 
 
 if __name__ == "__main__":

@@ -156,3 +156,17 @@ def test_batches_larger_than_the_engine_workspace(wm):
     assert model.encode(feats).shape == [5, 1500, cfg.d_model]
     with pytest.raises(ValueError):
         model.generate(enc, [prompt] * 5, beam_size=6)          # beam_size is bounded by max_beam_size
+
+
+def test_empty_audio(wm):
+    """the reference's tests/test_transcribe.py:91-97: an empty recording yields no segments on either driver and
+    language detection still answers — here on the engine (zero-sample log-mel, one all-padding window)"""
+    from faster_whisper_amd.transcribe import BatchedInferencePipeline
+    cfg, w, model = wm
+    audio = np.asarray([], dtype="float32")
+    assert list(model.transcribe(audio)[0]) == []
+    no_probs = np.zeros(0, dtype=np.float32)                # the Silero pass over zero windows
+    segs, info = BatchedInferencePipeline(model).transcribe(audio, vad_speech_probs=no_probs)
+    assert list(segs) == [] and info.duration == 0.0
+    lang, prob, all_probs = model.detect_language(audio)
+    assert lang in model.supported_languages and 0.0 < prob <= 1.0 and len(all_probs) == cfg.n_langs

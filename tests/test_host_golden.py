@@ -190,3 +190,15 @@ def test_batches_in_flight_keep_the_serial_result(gold, hf_tok, name):
     for i, (g, w) in enumerate(zip(segments, want)):
         _close(g, w, f"{name}.segments[{i}]")
     assert [c[0] for c in model.model.calls].count("generate") >= 4
+
+
+def test_empty_audio(hf_tok):
+    """the reference's tests/test_transcribe.py:91-97 on the host code: an empty recording yields no segments on either
+    driver, and language detection still answers"""
+    model = make_model(get_config("micro"), hf_tok)
+    audio = np.asarray([], dtype="float32")
+    assert list(model.transcribe(audio)[0]) == []
+    segs, info = BatchedInferencePipeline(model).transcribe(audio, vad_speech_probs=np.zeros(0, dtype=np.float32))
+    assert list(segs) == [] and info.duration == 0.0
+    lang, prob, all_probs = model.detect_language(audio)
+    assert lang in ("zh", "es", "en", "de") and 0.0 < prob <= 1.0 and len(all_probs) >= 1
