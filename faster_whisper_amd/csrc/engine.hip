@@ -1115,6 +1115,12 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   Model* m = &fm->impl;
   FW_CHECK_ARG(!m->decoder, "this model has joined another model's decoder");
   FW_CHECK_ARG(decode_batch >= 1, "decode_batch must be positive");
+  {
+    // the workspaces (and the second lane's model) are rebuilt below: not while the group has work
+    std::lock_guard<std::mutex> gl(m->grp.mu);
+    FW_CHECK_ARG(m->grp.active_runs == 0 && !m->grp.gathering && m->grp.queue.empty(),
+                 "decode runs are queued or in flight: set the decode batch before the first generate call or after the last one returned");
+  }
   std::lock_guard<std::mutex> lk(m->dec_mu);
   FW_HIP(hipSetDevice(m->device));
   // Whole encoder batches, at least one, at most 2048 rows, in 70 % of the free HBM.  The cross-attention cache is

@@ -161,6 +161,7 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
  *       run of calls with a short max_length holds more chunks than one that asks for the whole text context.  From
  *       four encoder batches on, the group decodes on TWO lanes (two workspaces, two streams, the budget covers both):
  *       two decode runs are in flight at once, the HBM-bound cross-attention of one beside the linears of the other;
+ *       setup-time call: FW_EINVAL while the group has decode runs queued or in flight;
  *   fw_model_join_decoder(worker, primary)  frees the worker's own decode workspace and routes its fw_generate /
  *       fw_detect_language / fw_align calls to the primary's.
  * fw_generate calls with identical options that arrive from different host threads while a decode run is in

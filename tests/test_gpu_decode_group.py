@@ -222,3 +222,33 @@ def test_decode_lanes_switch():
         for i in range(4):
             for a, b in zip(out[i], ref[i]):
                 assert a.sequences_ids == b.sequences_ids and a.scores == b.scores, (lanes, i)
+
+
+def test_decode_batch_cannot_change_under_a_run():
+    """fw_model_set_decode_batch rebuilds the decode workspaces (and the second lane): refused with FW_EINVAL while the
+    group has a run in flight, accepted again once it is idle — and results after a resize are what they were"""
+    cfg, model = _model("micro", 4)
+    lib, h = model._lib, model._replicas[0].handle
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    batch = _batches(1, 3)[0]
+    enc = model.encode_pcm(batch)
+    long_kw = dict(beam_size=5, max_length=len(prompt) + 400, min_new_tokens=400, return_scores=True)
+    short_kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True)
+    ref = model.generate(enc, [prompt] * 3, **short_kw)
+    runs0 = model.decode_stats()["runs"]
+    t = threading.Thread(target=lambda: model.generate(enc, [prompt] * 3, **long_kw))
+    t.start()
+    import time
+    t_end = time.time() + 30
+    while model.decode_stats()["runs"] == runs0 and time.time() < t_end:
+        time.sleep(0.0005)                            # the long run has started
+    rc = lib.fw_model_set_decode_batch(h, 6)
+    still_running = t.is_alive()
+    t.join()
+    if still_running:                                 # (400 steps of the micro model: tens of milliseconds)
+        assert rc != 0 and "in flight" in lib.fw_last_error().decode()
+    assert lib.fw_model_set_decode_batch(h, 6) == 0 and model.decode_stats()["decode_batch"] == 6
+    out = model.generate(model.encode_pcm(batch), [prompt] * 3, **short_kw)
+    for a, b in zip(out, ref):
+        assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
+    assert lib.fw_model_set_decode_batch(h, 12) == 0 and model.decode_stats()["decode_batch"] == 12
