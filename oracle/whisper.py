@@ -117,14 +117,24 @@ class OracleWhisper:
         one = torch.tensor(127.0, dtype=torch.float32)
         inv = torch.where(amax > 0, one / amax, torch.zeros_like(amax))
         ds = torch.where(amax > 0, amax / one, torch.ones_like(amax))
-        q = torch.round(x * inv.unsqueeze(-1)).to(torch.int32)
+        q = torch.round(x * inv.unsqueeze(-1))            # the int8 codes, held as float32 (exact: |q| <= 127)
         return q, ds
 
+    QK_BLOCK = 1024      # 127 * 127 * 1024 < 2^24: a float32 product over that many codes is an exact integer
+
     def _qmatmul(self, x: torch.Tensor, key: str) -> torch.Tensor:
-        """int8_float16 Dense core: quantise the rows of x, exact integer product, de-quantise"""
+        """int8_float16 Dense core: quantise the rows of x, exact integer product, de-quantise.
+        The integer product runs on float32 BLAS over K blocks of 1024 (every partial sum of a block is an integer
+        below 2^24, so each block is exact whatever the summation order); the blocks are added in float64 (exact:
+        |acc| < 2^53) — the same integers an int64 product gives (tests/test_oracle_int8.py), at the speed of sgemm and
+        without converting the weights on every call."""
         wq, ws = self.q[key]
         xq, xs = self._quant_rows(x)
-        acc = torch.matmul(xq.double(), wq.double().t())        # exact: |acc| < 2^53
+        K = xq.shape[-1]
+        acc = None
+        for k0 in range(0, K, self.QK_BLOCK):
+            part = torch.matmul(xq[..., k0:k0 + self.QK_BLOCK], wq[:, k0:k0 + self.QK_BLOCK].t()).double()
+            acc = part if acc is None else acc + part
         return acc.float() * xs.unsqueeze(-1) * ws
 
     def _dense(self, x: torch.Tensor, key: str, bias_key: Optional[str]) -> torch.Tensor:
@@ -173,6 +183,18 @@ class OracleWhisper:
 
     def _attn(self, q, k, v, mask=None, return_probs=False):
         """q [B,H,Tq,64] (unscaled), k/v [B,H,Tk,64]; softmax(q k^T / 8) v"""
+        if q.shape[0] > 1 and k.shape[0] == q.shape[0] and k.stride(0) == 0 and v.stride(0) == 0 and mask is None:
+            # the rows share ONE K/V (the beams of a chunk: cross K/V expanded over the beam axis).  Same arithmetic
+            # with the rows folded into the query axis — a batched matmul over the expanded view would first copy
+            # K and V once per row (38 MB per layer and step at large-v3).
+            R, H, Tq, _ = q.shape
+            qf = q.permute(1, 0, 2, 3).reshape(1, H, R * Tq, 64)
+            out = self._attn(qf, k[:1], v[:1], None, return_probs)
+            o, p = out if return_probs else (out, None)
+            o = o.reshape(R, Tq, H * 64)
+            if return_probs:
+                return o, p.reshape(H, R, Tq, -1).permute(1, 0, 2, 3)
+            return o
         s = torch.matmul(q * 0.125, k.transpose(-1, -2))
         if mask is not None:
             s = s + mask

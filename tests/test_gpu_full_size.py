@@ -74,6 +74,21 @@ def lv3():
     return cfg, synthetic_weights(cfg, seed=1234)
 
 
+_ORACLES = {}
+
+
+def _oracle(cfg, w, i8):
+    """the oracle of a geometry / compute type, built once per test session (rounding 1.5 G weights to fp16 — and
+    quantising them for int8 — takes as long as several of the checks below)"""
+    from oracle.whisper import OracleWhisper
+    key = (cfg.name, bool(i8), id(w))
+    if key not in _ORACLES:
+        _ORACLES[key] = OracleWhisper(cfg, w, emulate_fp16=True, int8=i8)
+    o = _ORACLES[key]
+    o.fold_ln = False
+    return o
+
+
 def _chunks():
     out = [bench_audio(480000, seed=100 + i) for i in range(B)]
     out[5] = out[5][:200000]          # ragged: a short chunk and an empty one ride along
@@ -84,7 +99,6 @@ def _chunks():
 def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
     from faster_whisper_amd import Whisper
     from faster_whisper_amd.backend import StorageView, language_token_strings
-    from oracle.whisper import OracleWhisper
     i8 = compute_type == "int8_float16"
     # Tolerances: NORTH_STAR everywhere except the listed EXCEPTIONS (module header).  Encoder output: relative max /
     # rms error of one chunk (not a log-prob; the decoder quantities below are what the north star constrains).
@@ -100,7 +114,7 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
     tag = f"[{cfg.name} {compute_type}]"
     model = Whisper(f"synthetic:{cfg.name}", device="cuda", files={"config": cfg, "weights": w},
                     compute_type=compute_type, max_batch_size=B, max_beam_size=5)
-    oracle = OracleWhisper(cfg, w, emulate_fp16=True, int8=i8)
+    oracle = _oracle(cfg, w, i8)
     chunks = _chunks()
 
     # ---- encoder: one chunk against the oracle, the batch against itself ----
@@ -212,7 +226,6 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
     import threading
     import time
     from faster_whisper_amd import Whisper
-    from oracle.whisper import OracleWhisper
     i8 = compute_type == "int8_float16"
     tag = f"[{cfg.name} {compute_type} merged]"
     model = Whisper(f"synthetic:{cfg.name}", device="cuda", files={"config": cfg, "weights": w},
@@ -277,7 +290,7 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
             assert a.sequences_ids == b.sequences_ids, (tag, i, j)
             assert a.scores == b.scores and a.no_speech_prob == b.no_speech_prob, (tag, i, j, a.scores, b.scores)
     # ---- the oracle on the first and the last chunk of the merged run ----
-    oracle = OracleWhisper(cfg, w, emulate_fp16=True, int8=i8)
+    oracle = _oracle(cfg, w, i8)
     okw = {k: v for k, v in kw.items() if k not in ("return_scores", "return_no_speech_prob")}
     tb = tolerance(cfg.name, compute_type, "beam")
     for (i, j) in oracle_chunks:

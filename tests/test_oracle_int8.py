@@ -44,6 +44,28 @@ def test_qmatmul_is_exact_integer_product():
     assert np.abs(y.numpy() - full).max() / np.abs(full).max() < 3e-2
 
 
+def test_qmatmul_is_exact_at_the_largest_magnitudes():
+    """every code +-127 over K = 5120 (the largest reduction of large-v3): |acc| reaches 127 * 127 * 5120 = 8.3e7, past
+    what ONE float32 accumulation holds exactly — the blocked product must still give the int64 integers"""
+    cfg = get_config("micro")
+    o = OracleWhisper(cfg, synthetic_weights(cfg, seed=3), int8=True)
+    rng = np.random.default_rng(4)
+    K, N = 5120, 96
+    sw = rng.choice([-1.0, 1.0], size=(N, K)).astype(np.float32)
+    sw[0], sw[1] = 1.0, -1.0                          # a row that adds up to +-127 * 127 * K against an all-ones x
+    sx = rng.choice([-1.0, 1.0], size=(5, K)).astype(np.float32)
+    sx[0] = 1.0
+    o.q["worst"] = OracleWhisper._quant_rows(torch.from_numpy(sw * 0.5))
+    x = torch.from_numpy(sx * 3.0)
+    y = o._qmatmul(x, "worst")
+    wq, ws = o.q["worst"]
+    xq, xs = o._quant_rows(x)
+    assert float(wq.abs().min()) == 127.0 and float(xq.abs().min()) == 127.0
+    acc = xq.numpy().astype(np.int64) @ wq.numpy().astype(np.int64).T
+    assert int(np.abs(acc).max()) == 127 * 127 * K
+    assert np.array_equal(y.numpy(), acc.astype(np.float32) * xs.numpy()[:, None] * ws.numpy()[None, :])
+
+
 def test_int8_oracle_tracks_float_oracle():
     cfg = get_config("micro")
     w = synthetic_weights(cfg, seed=5)
