@@ -78,11 +78,16 @@ _ORACLES = {}
 
 
 def _oracle(cfg, w, i8):
-    """the oracle of a geometry / compute type, built once per test session (rounding 1.5 G weights to fp16 — and
-    quantising them for int8 — takes as long as several of the checks below)"""
+    """the oracle of a geometry / compute type: built once for the tests that follow one another with the same key
+    (rounding 1.5 G weights to fp16 — and quantising them for int8 — takes as long as several of the checks below).
+    ONE is kept at a time (an fp32 large-v3 oracle is 6-12 GB of host memory): the tests of a compute type are
+    defined next to each other at the end of this file."""
+    import gc
     from oracle.whisper import OracleWhisper
     key = (cfg.name, bool(i8), id(w))
     if key not in _ORACLES:
+        _ORACLES.clear()
+        gc.collect()
         _ORACLES[key] = OracleWhisper(cfg, w, emulate_fp16=True, int8=i8)
     o = _ORACLES[key]
     o.fold_ln = False
@@ -194,27 +199,6 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
     assert not fails, fails
 
 
-def test_large_v3_float16(lv3):
-    cfg, w = lv3
-    _run(cfg, w, "float16")
-
-
-def test_large_v3_int8_float16(lv3):
-    cfg, w = lv3
-    _run(cfg, w, "int8_float16", tf_steps=8, beam_steps=48)
-
-
-def test_distil_large_v3_float16(lv3):
-    """C5 geometry: the large-v3 encoder with a 2-layer decoder (synthetic weights are seeded per tensor name, so
-    the distil model is the matching subset of the large-v3 set)"""
-    from faster_whisper_amd import get_config
-    from faster_whisper_amd.weights import weight_shapes
-    _, w = lv3
-    cfg = get_config("distil-large-v3")
-    wd = {k: w[k] for k in weight_shapes(cfg)}
-    _run(cfg, wd, "float16", tf_steps=12, beam_steps=48)
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # Merged decode runs at the benchmarked geometry (what bench.py executes: the generate() calls of the workers of a
 # GPU share one decode run).  8 workers x 16 chunks x beam 5 = 640 rows in ONE run: the row-group paths of the
@@ -303,11 +287,36 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
         assert d < tolerance(cfg.name, compute_type, "nsp"), (tag, i, j, d)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The tests, in the order they run: those that share an oracle (same geometry, same compute type) follow one another,
+# so that `_oracle` builds each of the three oracles once and holds one at a time.
+# ---------------------------------------------------------------------------------------------------------------
+def test_large_v3_float16(lv3):
+    cfg, w = lv3
+    _run(cfg, w, "float16")
+
+
 def test_merged_run_large_v3_float16(lv3):
     cfg, w = lv3
     _merged(cfg, w, "float16")
 
 
+def test_large_v3_int8_float16(lv3):
+    cfg, w = lv3
+    _run(cfg, w, "int8_float16", tf_steps=8, beam_steps=48)
+
+
 def test_merged_run_large_v3_int8_float16(lv3):
     cfg, w = lv3
     _merged(cfg, w, "int8_float16", oracle_chunks=((7, 15),))
+
+
+def test_distil_large_v3_float16(lv3):
+    """C5 geometry: the large-v3 encoder with a 2-layer decoder (synthetic weights are seeded per tensor name, so
+    the distil model is the matching subset of the large-v3 set)"""
+    from faster_whisper_amd import get_config
+    from faster_whisper_amd.weights import weight_shapes
+    _, w = lv3
+    cfg = get_config("distil-large-v3")
+    wd = {k: w[k] for k in weight_shapes(cfg)}
+    _run(cfg, wd, "float16", tf_steps=12, beam_steps=48)
