@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 mkdir -p build
 pids=()
 for f in logmel gemm rowops attn_enc engine decoder dec_kernels vad; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ dec_kernels.h -nt build/$f.o ] || [ ../../include/fwamd.h -nt build/$f.o ] || [ vad_model.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ dec_kernels.h -nt build/$f.o ] || [ ../../include/fwamd.h -nt build/$f.o ] || [ ../../include/fwamd_test.h -nt build/$f.o ] || [ vad_model.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
