@@ -105,6 +105,12 @@ out = bench.main(["--gpus", os.environ["WORLD_SIZE"], "--model", "micro", "--bat
                   "--no-cpu-baseline"], backend_factory=factory, dist_backend="gloo")
 if int(os.environ["RANK"]) != 0:
     print("RANK_DONE", flush=True)
+if os.environ.get("FW_SERIAL_DIGEST"):
+    # the same recording through the unsharded pipeline on a fresh scripted backend (no process group any more)
+    from faster_whisper_amd import get_config
+    cfg = get_config("micro")
+    serial = bench.pipeline_rtf(FakeBackend(cfg, 2, None), cfg, 11, 4, 5, 12, shard=False)
+    print("SERIAL " + json.dumps(serial), flush=True)
 '''
 
 
@@ -125,6 +131,9 @@ def test_bench_two_ranks_over_gloo(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), FW_ROOT=ROOT, OMP_NUM_THREADS="1")
+        env.pop("FWAMD_DIST_AT_WORLD_1", None)
+        if rank == 0:
+            env["FW_SERIAL_DIGEST"] = "1"
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=280) for p in procs]
@@ -141,5 +150,28 @@ def test_bench_two_ranks_over_gloo(tmp_path):
     assert "error" not in sh, sh
     # rank 0 yielded every chunk of the recording, in order: one segment per 30 s chunk
     assert sh["segments"] == 11 and sh["scaling"] == "strong" and sh["n_gpus"] == 2 and sh["tokens"] == 11 * 12
+    # ... and they are the unsharded pipeline's segments: same digest (ids, avg_logprob, no_speech_prob, in order)
+    serial = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("SERIAL ")][0][7:])
+    assert "error" not in serial and sh["digest"] == serial["digest"], (sh, serial)
     assert j["roofline"]["kernel"] == "dec_cross_attn" and j["roofline"]["bound"] == "hbm"
     assert "cpu_baseline" not in j and "pipeline" not in j      # N = 1 only
+
+
+@pytest.mark.timeout(300)
+def test_bench_one_rank_takes_the_multi_rank_flow(tmp_path):
+    """FWAMD_DIST_AT_WORLD_1=1: ONE rank runs the N > 1 control flow (what tests/test_gpu_rccl_world1.py does over RCCL on a
+    GPU box) — here over gloo; the sharded recording, assembled on rank 0 from the gathered records, must carry the digest
+    (ids, avg_logprob, no_speech_prob of every segment, in order) of the unsharded pipeline"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               FW_ROOT=ROOT, OMP_NUM_THREADS="1", FWAMD_DIST_AT_WORLD_1="1", FW_SERIAL_DIGEST="1")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and "pipeline" not in j and "cpu_baseline" not in j      # the N > 1 flow was taken
+    sh = j["sharded_recording"]
+    serial = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("SERIAL ")][0][7:])
+    assert "error" not in sh and "error" not in serial, (sh, serial)
+    assert sh["segments"] == serial["segments"] == 11 and sh["tokens"] == serial["tokens"] == 11 * 12
+    assert sh["digest"] == serial["digest"]
