@@ -8,6 +8,7 @@ on their own) -> ids/scores back on the host (+ gather to 
 metric = audio seconds per wall second (whole job, all ranks).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (no rank environment: launches its own N ranks, see relaunch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -158,6 +159,47 @@ def build_backend(args, cfg, rank, world, local_rank):
     return model, weights
 
 
+def relaunch(argv, n):
+    """`python bench.py --gpus N` without a rank environment: start N ranks of this script under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1, a free port) and hand their exit status back.  Rank 0 of the child
+    job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_seam():
+    """FWAMD_BENCH_SEAM=<file.py>: a test seam for fresh `python bench.py` processes (tests/test_bench_dist_gloo.py) —
+    the file defines `factory(args, cfg, rank, world, local_rank) -> (backend, weights)` and `DIST_BACKEND`.  The
+    benchmark itself never sets it."""
+    path = os.environ.get("FWAMD_BENCH_SEAM")
+    if not path:
+        return None, None
+    import runpy
+    ns = runpy.run_path(path)
+    return ns["factory"], ns.get("DIST_BACKEND")
+
+
+def oracle_rev():
+    """content hash of the CPU oracle the cpu_baseline leg times (the repository's .git does not travel to the GPU
+    box): two bench lines are comparable on `cpu_baseline` only when this agrees"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("whisper.py", "logmel.py"):
+        with open(os.path.join(ROOT, "oracle", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,9 +238,20 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     """backend_factory / dist_backend: test seams (tests/test_bench_dist_gloo.py runs the N > 1 control flow on CPU
     with a scripted backend over gloo); the benchmark itself never passes them."""
     args = parse_args(argv)
+    if backend_factory is None and dist_backend is None:
+        backend_factory, dist_backend = load_seam()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this process: be the launcher (one rank per GPU), then leave with the job's status
+        rc = relaunch(sys.argv[1:] if argv is None else list(argv), args.gpus)
+        if rc:
+            raise SystemExit(rc)
+        return None
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): "
+                         "refusing to report a line for a different job size")
     dist = None
     on_gpu = dist_backend in (None, "nccl")
     multi = _multi(world)
@@ -261,12 +314,11 @@ def main(argv=None, backend_factory=None, dist_backend=None):
 
     def run_steps(n, n_tok=L, gather=True):
         futs = [pool.submit(step, n_tok) for _ in range(n)]
-        outs = []
-        for f in futs:                   # results come back in submission order = chunk order
-            r = f.result()
-            if multi and gather:
-                gather_results(r, n_tok, rank, world, local_rank)
-            outs.append(r)
+        outs = [f.result() for f in futs]          # results come back in submission order = chunk order
+        if multi and gather:
+            # ONE gather per timed region (the path has no collective inside it: DESIGN.md section 7): the fixed-size
+            # records of every step of this rank travel to rank 0 together, in rank order
+            gather_results([r for o in outs for r in o], n_tok, rank, world, local_rank)
         return outs
 
     last = {}
@@ -317,7 +369,9 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         "config": {"workload": f"{args.model} {args.compute_type} BatchedInferencePipeline hot path: {args.batch} x 30 s "
                                f"chunks/step, beam_size={args.beam}, {L} new tokens/chunk (fixed), PCM resident in HBM",
                    "global_batch": args.batch * world, "new_tokens": L, "workers_per_gpu": W, "decode_lanes": lanes,
-                   "decode_group": {"capacity_chunks": stats1["decode_batch"], "decode_runs": runs,
+                   "decode_group": {"capacity_chunks": stats1["decode_batch"],
+                                    "run_capacity_chunks": stats1.get("run_capacity", stats1["decode_batch"]),
+                                    "decode_runs": runs,
                                     "chunks_per_run": round((stats1["chunks"] - stats0["chunks"]) / runs, 1),
                                     "largest_run_chunks": stats1["max_run_chunks"]},
                    "steady_state": args.steps >= 2 * W,
@@ -327,6 +381,12 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                    "model_load_s": round(load_s, 1)},
     }
 
+    # the combined roofline ceiling of this configuration (encoder MFMA + decode HBM, L = 100) is
+    # 4 525x per GPU; L = 224: 2 211x
+    ceiling = {100: 4525.0, 224: 2211.0}
+    if args.model == "large-v3" and args.compute_type == "float16" and L in ceiling:
+        out["roofline_combined"] = {"value_over_ceiling": round(value / (ceiling[L] * world), 4),
+                                    "ceiling_per_gpu": ceiling[L], "source": "SURVEY.md section 8d"}
     secondary = not args.no_secondary
     # ---- secondary, all ranks take part: steady state, the cap case and (N > 1) the sharded recording ----
     if secondary and args.steps < 2 * W:
@@ -334,6 +394,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         dts = timed(ns)
         out["steady"] = {"value": round(30.0 * args.batch * ns * world / dts, 2), "unit": "audio-seconds per wall-second",
                          "steps": ns, "ms_per_step": round(1000.0 * dts / ns, 3)}
+        if "roofline_combined" in out:
+            out["roofline_combined"]["steady_over_ceiling"] = round(out["steady"]["value"] / (ceiling[L] * world), 4)
     if secondary:
         n2 = max(W, min(args.steps, 2 * W))
         run_steps(W, 224, gather=False)        # graph capture etc. for the other decode length
@@ -368,7 +430,10 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             # instantiations of dec_gemm_frag_kernel (LayerNorm-folded / plain / long-K), timed here as four role
             # families (qkv, d x d, ffn1, ffn2): together they are listed under roofline_others as "dec_gemm".
             rows_per_run = args.beam * (stats1["chunks"] - stats0["chunks"]) / runs
-            gemm_shaped = rows_per_run >= 320      # merged runs: the decoder linears are GEMMs, not weight streams
+            # runs of at least DEC_BIG_MIN_ROWS rows take the GEMM-shaped kernel (dec_gemm_big_kernel) and are priced against
+            # the MFMA roof; below it the linears are weight-streaming launches priced against HBM
+            big_rows = model.dec_big_min_rows() if hasattr(model, "dec_big_min_rows") else 1024
+            gemm_shaped = rows_per_run >= big_rows
 
             def roof_of(name, v):
                 if name in MFMA_FAMILIES or (name == "dec_gemm" and gemm_shaped):
@@ -410,9 +475,10 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                                     else v["bytes"] > 0)}
             if "dec_gemm" in out["roofline_others"]:
                 out["roofline_others"]["dec_gemm"]["note"] = (
-                    f"decode runs of {rows_per_run:.0f} rows on average: the six per-layer linears are GEMM-shaped and priced "
-                    "against the MFMA roof" if gemm_shaped else
-                    "solo decode runs (80 rows): weight-streaming launches, latency-bound, priced against the HBM roof")
+                    f"decode runs of {rows_per_run:.0f} rows on average (>= {big_rows}: dec_gemm_big_kernel): the six per-layer "
+                    "linears are GEMM-shaped and priced against the MFMA roof" if gemm_shaped else
+                    f"decode runs of {rows_per_run:.0f} rows on average (< {big_rows}: the register-streaming kernel): "
+                    "weight-streaming launches, priced against the HBM roof")
             out["roofline"] = roof
             out["families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in rep.items()}
             out["families_sum_ms"] = round(tot, 3)
@@ -440,6 +506,10 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if not verified:
+        # a merged run that does not reproduce the solo run bit for bit is a wrong result, not a slow one
+        raise SystemExit("bench.py: the last batch of the timed region differs from the same batch decoded alone "
+                         "(`verified`: false) — the line above must not be used")
     return out
 
 
@@ -564,7 +634,7 @@ def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
     fixed = max(0.0, t1 - per_step)              # cross-K/V projection + prompt forward
     total = t_mel + t_enc + fixed + per_step * L
     return {"value": round(30.0 / total, 4), "unit": "audio-seconds per wall-second", "cores": cores,
-            "host_cores": host_cores, "kind": "port",
+            "host_cores": host_cores, "kind": "port", "oracle_sha16": oracle_rev(),
             "sample": f"1 chunk (30 s): numpy log-mel {t_mel:.2f}s; the whole encoder measured {t_enc:.1f}s; cross-KV+prompt "
                       f"{fixed:.2f}s; {n_meas} beam-{beam} steps measured ({per_step * 1e3:.0f} ms/step) -> {L} steps "
                       f"(a step's cost does not depend on its index: KV-cached); torch fp32 restatement (oracle/) on {cores} "

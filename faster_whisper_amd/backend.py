@@ -323,7 +323,12 @@ class Whisper:
         _lib.check(self._lib.fw_model_decode_stats(self._replicas[0].handle, C.byref(runs), C.byref(reqs),
                                                    C.byref(chunks), C.byref(mx)))
         return {"runs": runs.value, "requests": reqs.value, "chunks": chunks.value, "max_run_chunks": mx.value,
-                "decode_batch": int(self._lib.fw_model_decode_batch(self._replicas[0].handle))}
+                "decode_batch": int(self._lib.fw_model_decode_batch(self._replicas[0].handle)),
+                "run_capacity": int(self._lib.fw_model_run_capacity(self._replicas[0].handle))}
+
+    def dec_big_min_rows(self) -> int:
+        """rows from which a decode run's linears take the GEMM-shaped kernel (bench.py prices them accordingly)"""
+        return int(self._lib.fw_dec_big_min_rows())
 
     def _replica_for(self, features: Optional[StorageView]) -> _Replica:
         if features is not None and features._owner is not None:

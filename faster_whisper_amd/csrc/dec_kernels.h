@@ -31,8 +31,11 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int cache_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag);
+// slot_map: [B / kv_div] encoder chunk of the run -> chunk slot behind ck / cvt (the cross-attention pool)
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
-                       int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag);
+                       int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map);
+// rows from which launch_dec_gemm_frag hands a decode run's linears to the GEMM-shaped kernel
+int dec_big_min_rows();
 // frag = 1: `out` is a fragment-major [rows/16][d/32][64][8] buffer (input of launch_dec_gemm_frag)
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,

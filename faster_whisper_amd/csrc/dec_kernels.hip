@@ -13,6 +13,7 @@
 #include "common.h"
 #include "dec_kernels.h"
 #include <stdlib.h>
+#include <atomic>
 
 // ------------------------------------------------------------------------------------
 // K12: token + learned-position embedding  x[r] = E[tok[r]] + pos[p]
@@ -853,14 +854,18 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
                                                              const half_t* __restrict__ ck,
                                                              const half_t* __restrict__ cvt, int T, int kvp,
                                                              int kmul, half_t* __restrict__ out,
-                                                             const int* __restrict__ done, int kv_div, int frag) {
+                                                             const int* __restrict__ done, int kv_div, int frag,
+                                                             const int* __restrict__ slot_map) {
   __shared__ float sm[CA_WAVES][16], sl[CA_WAVES][16];
   __shared__ float so[CA_WAVES][16][65];
   const int h = blockIdx.x, c = blockIdx.y;
   if (done && done[c]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int ce = c / kv_div;   // encoder chunk whose K / V^T this decode chunk attends to
+  // encoder chunk whose K / V^T this decode chunk attends to, and the slot of the cross-attention pool that holds it
+  // (the pool is shared by the decode lanes of the device: a run's chunks are wherever their encoder outputs were given
+  //  a block, decoder.hip: CrossPool)
+  const int ce = slot_map[c / kv_div];
   const half_t* kbase = ck + ((size_t)ce * (d >> 6) + h) * kvp * 64 + lane * 8;   // [chunk][head][group][run][lane][8]
   const half_t* vbase = cvt + ((size_t)ce * (d >> 6) + h) * kvp * 64 + lane * 8;
   half8_t qf[2];
@@ -1462,18 +1467,24 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
 // (measured next to 256 x 64, 128 x 256, 8 waves on 128 x 128, deeper rings, two k-steps per barrier, LDS reads
 //  software-pipelined under the MFMAs, L2 touch-ahead: profiles/r03_dec_linear_bench.txt — none better)
 template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
-static void big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
+static int big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
   constexpr int lds = (4 * WM + FB * WN) * KC * 1024 * NST;
-  static bool attr_set = false;   // (per instantiation)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  // the dynamic-LDS limit is a per-device attribute of the function; decode lanes launch from several host threads:
+  // one bit per device, set after the attribute call returned (two threads may both make the call: it is idempotent)
+  static std::atomic<unsigned long long> attr_done{0};   // (per instantiation)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return -1;
+    attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int nMt = ((R + 15) / 16 + 4 * WM - 1) / (4 * WM), nNt = (N / 16 + FB * WN - 1) / (FB * WN);
   dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
                                                                                       out_frag, R, N, K, act, nNt);
+  return hipPeekAtLastError() == hipSuccess ? 0 : -1;
 }
 template <int WM, int WN, int FB, int KC, int NST>
 static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
@@ -1484,10 +1495,9 @@ static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const hal
   if (KS % S != 0 || (KS / S) % KC != 0 || KS / KC < NST) return -1;
   if ((ldo % 8) || (res && (ldr % 8))) return -1;   // 16-byte row segments
 #define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, FB, KC, NST>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
-  if (s1) { if (S == 8) DGB(true, 8); else DGB(true, 4); }
-  else { if (S == 8) DGB(false, 8); else DGB(false, 4); }
+  if (s1) return S == 8 ? DGB(true, 8) : DGB(true, 4);
+  return S == 8 ? DGB(false, 8) : DGB(false, 4);
 #undef DGB
-  return 0;
 }
 int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
@@ -1556,6 +1566,8 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
     return 0;
   return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
 }
+
+int dec_big_min_rows() { return DEC_BIG_MIN_ROWS; }
 
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
@@ -1661,11 +1673,11 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
-                       int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag) {
+                       int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map) {
   // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup (4 waves measured slower)
   // the K / V^T stream is read once per step and never again before 15 GB of other chunks have passed: non-temporal
   // loads (measured 75.3 -> 68.3 ms per batch, 5.4 -> 5.9 TB/s)
-  dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag);
+  dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag, slot_map);
 }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {

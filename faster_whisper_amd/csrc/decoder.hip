@@ -38,6 +38,23 @@ using fwd::GenDev;
 // rows of a merged decode run above which a second, nearly empty round of workgroups starts (dec_kernels.hip)
 #define DEC_RUN_MAX_ROWS 1600
 
+// Cross-attention K / V^T pool of a decode group: n_blocks blocks of EB (= max_batch) chunk slots, layer-major
+// [L][n_blocks * EB][H][kvp * 64] (a layer's launch sees every slot of that layer behind one base pointer; a run reaches
+// its chunks through a slot table).  A block holds the projected K / V^T of ONE encoder output; fw_generate /
+// fw_detect_language / fw_align take the block that already holds their encoder output (a hit: generate after
+// detect_language, align after generate, the temperature ladder re-decoding a window) or the least recently used free
+// one.  A decode run takes all its blocks at once (no hold-and-wait between the lanes).
+struct CrossPool {
+  half_t *ck = nullptr, *cvt = nullptr;
+  int n_blocks = 0, EB = 0, kvp = 0;
+  struct Block { uint64_t enc_id = 0; int n = 0; bool busy = false; uint64_t stamp = 0; };
+  std::vector<Block> blocks;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t clock = 0;
+  int n_slots() const { return n_blocks * EB; }
+};
+
 struct GraphSlot {
   hipGraphExec_t exec = nullptr;
   GenDev key;
@@ -45,12 +62,9 @@ struct GraphSlot {
 };
 
 struct GenWorkspace {
-  int B = 0, K = 0, R = 0, NT = 0;       // capacity: chunks, beams per chunk, rows = B * K
+  int B = 0, K = 0, R = 0, NT = 0;       // capacity of a run: chunks, beams per chunk, rows = B * K
   int EB = 0;                            // chunks of one encoder output (the models' max_batch)
-  int kvp = 0;                           // encoder positions padded to the 32-key MFMA group
-  half_t *ck = nullptr, *cvt = nullptr;  // cross K / V^T [L][B][H][kvp*64], MFMA-fragment-major (dec_kernels.hip K14)
-  std::vector<uint64_t> slot_enc;        // per chunk slot: id of the encoder output whose K/V it holds (0 = none)
-  std::vector<int> slot_chunk;           //                 and which chunk of it
+  int* slot_map = nullptr;               // [R] chunk of the run -> chunk slot of the cross-attention pool (device)
   // self-attention cache: ONE allocation of L x self_cap x d halves per K and V, self_cap = R x NTs row-positions.
   // Its geometry is the RUN's: [L][rows of the run][H][ctx of the run][64] with rows x ctx <= self_cap, so a run
   // whose calls ask for max_length 104 holds 4.3x the rows of one that asks for the whole text context.
@@ -94,40 +108,130 @@ static int self_positions(const Model* m, int decode_batch, int nts) {
   return std::min(NT, std::max(std::max(nts, need), 8));
 }
 
-int64_t gen_workspace_bytes(const Model* m, int decode_batch, int nts) {
+int64_t gen_workspace_bytes(const Model* m, int lane_chunks, int nts) {
   const fw_config& c = m->cfg;
-  const int64_t B = decode_batch, R = B * m->max_beam, d = c.d_model, L = c.n_dec_layers, NT = c.n_text_ctx;
-  const int64_t kvp = ((c.n_audio_ctx + 31) / 32) * 32;
-  const int64_t NTs = self_positions(m, decode_batch, nts > 0 ? nts : (int)NT);
-  int64_t n = 2 * (L * B * d * kvp) * 2 + 2 * (L * R * NTs * d) * 2;   // cross K/V^T, self K/V (fp16)
+  const int64_t B = lane_chunks, R = B * m->max_beam, d = c.d_model, L = c.n_dec_layers, NT = c.n_text_ctx;
+  const int64_t NTs = self_positions(m, lane_chunks, nts > 0 ? nts : (int)NT);
+  int64_t n = 2 * (L * R * NTs * d) * 2;                               // self K/V (fp16)
   n += R * (int64_t)c.n_vocab * 4 + R * 12 * d * 2 * 2;                // logits, activations
   n += R * FIN_CAP * NT * 4 + 3 * R * NT * 4;                          // finished hypotheses, histories
   return n + (64 << 20);
 }
+
+int64_t cross_pool_bytes(const Model* m, int pool_chunks) {
+  const fw_config& c = m->cfg;
+  const int64_t kvp = ((c.n_audio_ctx + 31) / 32) * 32;
+  return 2 * ((int64_t)c.n_dec_layers * pool_chunks * c.d_model * kvp) * 2;   // K and V^T, fp16
+}
+
+// the pool of the group m decodes for: m's own (primary) or the primary's (a lane)
+static CrossPool* pool_of(Model* m) { return (m->pool_owner ? m->pool_owner : m)->xpool; }
+
+static int cross_pool_ensure(Model* m) {
+  Model* owner = m->pool_owner ? m->pool_owner : m;
+  if (owner->xpool) return FW_OK;
+  const fw_config& c = owner->cfg;
+  CrossPool* p = new CrossPool();
+  p->EB = owner->max_batch;
+  p->n_blocks = std::max(1, std::max(owner->decode_batch, owner->max_batch) / owner->max_batch);
+  p->kvp = ((c.n_audio_ctx + 31) / 32) * 32;
+  p->blocks.assign(p->n_blocks, CrossPool::Block());
+  const size_t n = (size_t)c.n_dec_layers * p->n_slots() * c.d_model * p->kvp;
+  int rc;
+  if ((rc = dev_alloc_t(&p->ck, n)) || (rc = dev_alloc_t(&p->cvt, n))) {
+    if (p->ck) (void)hipFree(p->ck);
+    delete p;
+    return rc;
+  }
+  // the padded keys (>= T) are never written: K garbage is masked, V^T must be 0 (0 * NaN)
+  hipError_t he = hipMemset(p->ck, 0, n * sizeof(half_t));
+  if (he == hipSuccess) he = hipMemset(p->cvt, 0, n * sizeof(half_t));
+  if (he == hipSuccess) he = hipDeviceSynchronize();
+  if (he != hipSuccess) {
+    (void)hipFree(p->ck); (void)hipFree(p->cvt);
+    delete p;
+    set_error("cross-attention pool setup failed: %s", hipGetErrorString(he));
+    return FW_ENODEV;
+  }
+  owner->xpool = p;
+  return FW_OK;
+}
+
+void cross_pool_free(Model* m) {
+  CrossPool* p = m->xpool;
+  if (!p) return;
+  if (p->ck) (void)hipFree(p->ck);
+  if (p->cvt) (void)hipFree(p->cvt);
+  delete p;
+  m->xpool = nullptr;
+}
+
+// Blocks for the encoder outputs `ids` (chunk counts `ns`), ALL of them or none: waits until enough blocks are free.
+// blk[i] = block index, hit[i] = the block already holds that encoder output's K / V^T.
+static void pool_acquire(CrossPool* p, const std::vector<uint64_t>& ids, const std::vector<int>& ns, std::vector<int>& blk,
+                         std::vector<char>& hit) {
+  std::unique_lock<std::mutex> lk(p->mu);
+  const int n = (int)ids.size();
+  blk.assign(n, -1);
+  hit.assign(n, 0);
+  for (;;) {
+    int n_free = 0;
+    for (const CrossPool::Block& b : p->blocks) n_free += b.busy ? 0 : 1;
+    if (n_free >= n) break;
+    p->cv.wait(lk);
+  }
+  for (int i = 0; i < n; ++i)          // first the hits ...
+    for (int k = 0; k < p->n_blocks; ++k) {
+      CrossPool::Block& b = p->blocks[k];
+      if (!b.busy && b.enc_id == ids[i] && b.n == ns[i] && ids[i] != 0) { b.busy = true; blk[i] = k; hit[i] = 1; break; }
+    }
+  for (int i = 0; i < n; ++i) {        // ... then the least recently used free blocks
+    if (blk[i] >= 0) continue;
+    int best = -1;
+    for (int k = 0; k < p->n_blocks; ++k)
+      if (!p->blocks[k].busy && (best < 0 || p->blocks[k].stamp < p->blocks[best].stamp)) best = k;
+    CrossPool::Block& b = p->blocks[best];
+    b.busy = true; b.enc_id = 0; b.n = 0;   // marked empty until the projection has been launched
+    blk[i] = best;
+  }
+  for (int i = 0; i < n; ++i) p->blocks[blk[i]].stamp = ++p->clock;
+}
+
+static void pool_release(CrossPool* p, const std::vector<int>& blk) {
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (int k : blk)
+      if (k >= 0) p->blocks[k].busy = false;
+  }
+  p->cv.notify_all();
+}
+
+struct PoolHold {   // releases its blocks when the decode run / detect_language / align call ends, however it ends
+  CrossPool* p;
+  std::vector<int> blk;
+  ~PoolHold() { if (p) pool_release(p, blk); }
+};
 
 static int gen_workspace_build(Model* m) {
   const fw_config& c = m->cfg;
   GenWorkspace* g = new GenWorkspace();
   m->gen = g;   // gen_workspace_ensure frees it again when anything below fails
   if (m->decode_batch < m->max_batch) m->decode_batch = m->max_batch;
-  g->B = m->decode_batch;
+  g->B = lane_chunks_of(m);
   g->EB = m->max_batch;
   g->K = m->max_beam;
   g->R = g->B * g->K;
   g->NT = c.n_text_ctx;
-  g->NTs = self_positions(m, m->decode_batch, m->decode_self_ctx > 0 ? m->decode_self_ctx : c.n_text_ctx);
+  g->NTs = self_positions(m, g->B, m->decode_self_ctx > 0 ? m->decode_self_ctx : c.n_text_ctx);
   g->self_cap = (int64_t)g->R * g->NTs;
-  g->kvp = ((c.n_audio_ctx + 31) / 32) * 32;
-  g->slot_enc.assign(g->B, 0);
-  g->slot_chunk.assign(g->B, 0);
   const size_t B = g->B, R = g->R, d = c.d_model, L = c.n_dec_layers, NT = g->NT;
+  (void)B;
   FW_CHECK_ARG(R <= 2048, "decode_batch * max_beam must be <= 2048 (got %zu)", R);
   FW_HIP(hipSetDevice(m->device));
   if (!m->dec_stream) FW_HIP(hipStreamCreateWithFlags(&m->dec_stream, hipStreamNonBlocking));
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
-  A(g->ck, L * B * d * g->kvp);
-  A(g->cvt, L * B * d * g->kvp);
+  A(g->slot_map, R);
   A(g->sk, L * (size_t)g->self_cap * d);
   A(g->sv, L * (size_t)g->self_cap * d);
   A(g->x, R * d); A(g->qkv, R * 3 * d); A(g->att, R * d); A(g->qc, R * d);
@@ -163,9 +267,7 @@ static int gen_workspace_build(Model* m) {
     FW_HIP(hipMemset(g->ffn_frag, 0, R16 * 4 * d * sizeof(half_t)));
   }
 #undef A
-  // the padded keys (>= T) are never written: K garbage is masked, V^T must be 0 (0 * NaN)
-  FW_HIP(hipMemset(g->ck, 0, L * B * d * g->kvp * sizeof(half_t)));
-  FW_HIP(hipMemset(g->cvt, 0, L * B * d * g->kvp * sizeof(half_t)));
+  FW_HIP(hipMemset(g->slot_map, 0, R * sizeof(int)));
   FW_HIP(hipMemset(g->zero_done, 0, R * sizeof(int)));
   FW_HIP(hipMemset(g->d_step, 0, sizeof(int)));
   FW_HIP(hipDeviceSynchronize());
@@ -177,8 +279,10 @@ static int gen_workspace_build(Model* m) {
 // A workspace is installed whole or not at all: after a failed build (argument check, out of HBM) the next call
 // starts from scratch instead of launching kernels on a half-allocated one.
 int gen_workspace_ensure(Model* m) {
+  int rc = cross_pool_ensure(m);
+  if (rc) return rc;
   if (m->gen) return FW_OK;
-  const int rc = gen_workspace_build(m);
+  rc = gen_workspace_build(m);
   if (rc) gen_workspace_free(m);
   return rc;
 }
@@ -188,7 +292,7 @@ void gen_workspace_free(Model* m) {
   if (!g) return;
   for (GraphSlot& s : g->graphs)
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
-  void* ptrs[] = {g->ck, g->cvt, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
+  void* ptrs[] = {g->slot_map, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_bits,
                   g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag};
@@ -198,16 +302,15 @@ void gen_workspace_free(Model* m) {
   m->gen = nullptr;
 }
 
-// K11: cross-attention K / V^T of every decoder layer for the chunks of one encoder output, written to the
-// chunk slots [b0, b0 + enc->B) of the decode workspace (once per generate call)
-static int ensure_cross_kv(Model* m, const Tensor* enc, int b0) {
-  GenWorkspace* g = m->gen;
-  const int B = enc->B;
-  bool hit = true;
-  for (int i = 0; i < B; ++i) hit = hit && g->slot_enc[b0 + i] == enc->id && g->slot_chunk[b0 + i] == i;
+// K11: cross-attention K / V^T of every decoder layer for the chunks of one encoder output, written to the chunk
+// slots of pool block `blk` (held by the caller; once per encoder output as long as the block is not recycled)
+static int ensure_cross_kv(Model* m, const Tensor* enc, int blk, bool hit) {
   if (hit) return FW_OK;
-  // a failure half way leaves the slots marked empty, never pointing at partly overwritten K/V
-  for (int i = 0; i < B; ++i) g->slot_enc[b0 + i] = 0;
+  GenWorkspace* g = m->gen;
+  CrossPool* pool = pool_of(m);
+  const int B = enc->B;
+  const int b0 = blk * pool->EB;
+  // (a failure half way leaves the block marked empty — pool_acquire did that — never pointing at partly overwritten K/V)
   const fw_config& c = m->cfg;
   const int d = c.d_model, T = c.n_audio_ctx;
   const int64_t xs = (int64_t)T * d;
@@ -215,12 +318,12 @@ static int ensure_cross_kv(Model* m, const Tensor* enc, int b0) {
   int rc;
   ProfScope ps(m, PF_CROSS_KV_GEMM, 2.0 * c.n_dec_layers * B * (double)T * d * (2.0 * d), 0, st);
   const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
-  const int kvp = g->kvp;
+  const int kvp = pool->kvp;
   const int64_t kvs = (int64_t)d * kvp;   // one chunk's K (or V^T): H heads x kvp keys x 64
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
-    half_t* kd = g->ck + ((size_t)l * g->B + b0) * kvs;
-    half_t* vd = g->cvt + ((size_t)l * g->B + b0) * kvs;
+    half_t* kd = pool->ck + ((size_t)l * pool->n_slots() + b0) * kvs;
+    half_t* vd = pool->cvt + ((size_t)l * pool->n_slots() + b0) * kvs;
     // both land in the MFMA-fragment-major layout of the decode kernel (head_rows = kvp selects it in the
     // GEMM epilogue): K through the plain epilogue, V^T through the transposed one
     if (i8) {
@@ -236,7 +339,11 @@ static int ensure_cross_kv(Model* m, const Tensor* enc, int b0) {
     if ((rc = run_linear(m, L.ck, enc->data, d, xs, kd, d, kvs, nullptr, 0, 0, T, B, 0, false, kvp, st))) return rc;
     if ((rc = run_linear(m, L.cv, enc->data, d, xs, vd, kvp, kvs, nullptr, 0, 0, T, B, 0, true, kvp, st))) return rc;
   }
-  for (int i = 0; i < B; ++i) { g->slot_enc[b0 + i] = enc->id; g->slot_chunk[b0 + i] = i; }
+  {
+    std::lock_guard<std::mutex> lk(pool->mu);
+    pool->blocks[blk].enc_id = enc->id;
+    pool->blocks[blk].n = B;
+  }
   return FW_OK;
 }
 
@@ -250,6 +357,7 @@ struct StepCfg {
   int nospeech_rowmul; // > 0: run the no-speech kernel on rows b*rowmul after the logits GEMM
   bool beam_tail;      // logits rules + beam update + step advance
   const int* done;     // per-chunk done flags for cross-attn early exit
+  int kv_slot0 = 0;    // align: first pool slot of the call's block (its chunks are contiguous there)
   // align extras
   const int* sel_heads_dev = nullptr;   // [n_sel_total] head ids, grouped per layer
   const int* sel_layer_off = nullptr;   // host: [L+1] offsets into sel_heads
@@ -270,6 +378,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   GenWorkspace* g = m->gen;
   const fw_config& c = m->cfg;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, NT = g->NT;
+  CrossPool* pool = pool_of(m);
+  const int kvp = pool->kvp;
   hipStream_t st = m->dec_stream;
   const int rows = s.rows;
   const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
@@ -297,8 +407,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     // the run's own cache geometry: [layer][cache_rows slots][H][ctx][64]
     half_t* kc = g->sk + (size_t)l * gp.cache_rows * gp.ctx * d;
     half_t* vc = g->sv + (size_t)l * gp.cache_rows * gp.ctx * d;
-    const half_t* ck = g->ck + (size_t)l * g->B * d * g->kvp;
-    const half_t* cvt = g->cvt + (size_t)l * g->B * d * g->kvp;
+    const half_t* ck = pool->ck + (size_t)l * pool->n_slots() * d * kvp;
+    const half_t* cvt = pool->cvt + (size_t)l * pool->n_slots() * d * kvp;
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
@@ -322,13 +432,13 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
       const int off = s.sel_layer_off[l], n = s.sel_layer_off[l + 1] - off;
-      fwd::launch_cross_probs(st, g->qc, d, ck, T, g->kvp, s.sel_heads_dev + off, n, s.n_sel_total,
+      fwd::launch_cross_probs(st, g->qc, d, ck + (size_t)s.kv_slot0 * d * kvp, T, kvp, s.sel_heads_dev + off, n, s.n_sel_total,
                               s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
     }
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * (s.B / gp.kv_div) * (double)T * d, st);
-      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, g->kvp, s.kmul, frag ? g->att_frag : g->att, s.B, H, s.done,
-                             gp.kv_div, frag);
+      fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, kvp, s.kmul, frag ? g->att_frag : g->att, s.B, H, s.done,
+                             gp.kv_div, frag, g->slot_map);
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d, st);
@@ -425,12 +535,15 @@ static bool mergeable(const GenRequest& a, const GenRequest& b) {
 }
 
 // chunks of a run led by `r` that fit the self-attention cache (before the workspace exists: its planned size)
-static int64_t self_chunk_capacity(Model* dm, const GenRequest& r) {
-  if (r.sampling) return r.B;
-  const int B = std::max(dm->decode_batch, dm->max_batch);
+static int64_t planned_self_cap(const Model* dm) {   // rows x positions of a lane's self-attention cache
+  const int B = lane_chunks_of(dm);
   const int nts = self_positions(dm, B, dm->decode_self_ctx > 0 ? dm->decode_self_ctx : dm->cfg.n_text_ctx);
-  const int64_t cap = (int64_t)B * dm->max_beam * nts;
-  return std::max<int64_t>(r.B, cap / ((int64_t)r.o->beam_size * run_ctx(dm->cfg, r.o->max_length, r.P)));
+  return (int64_t)B * dm->max_beam * nts;
+}
+static int64_t self_chunk_capacity(Model* dm, const GenRequest& r) {
+  // rows of one encoder chunk in the run: beam_size, or num_hypotheses beam-1 rows when sampling (kv_div)
+  const int64_t rows_per_chunk = r.sampling ? std::max(1, r.o->num_hypotheses) : r.o->beam_size;
+  return planned_self_cap(dm) / (rows_per_chunk * run_ctx(dm->cfg, r.o->max_length, r.P));
 }
 
 // Decode run over the concatenated chunks of `reqs` (all mergeable with reqs[0]).  Caller holds m->dec_mu.
@@ -455,11 +568,24 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   FW_CHECK_ARG((int64_t)Bx * K * ctx <= g->self_cap, "decode run of %d rows x %d positions exceeds the self-attention cache", Bx * K, ctx);
   FW_HIP(hipSetDevice(m->device));
   hipStream_t st = m->dec_stream;
+  // ---- the run's blocks of the cross-attention pool (all at once), the projection of those that are not there yet,
+  //      and the run's chunk -> pool slot table ----
+  CrossPool* pool = pool_of(m);
+  PoolHold hold{pool, {}};
+  std::vector<int> slot_host((size_t)Bx);
   {
-    int b0 = 0;
-    for (const GenRequest* r : reqs) {
-      if ((rc = ensure_cross_kv(m, r->enc, b0))) return rc;
-      b0 += r->B;
+    std::vector<uint64_t> ids;
+    std::vector<int> ns;
+    std::vector<char> hit;
+    for (const GenRequest* r : reqs) { ids.push_back(r->enc->id); ns.push_back(r->enc->B); }
+    FW_CHECK_ARG((int)reqs.size() <= pool->n_blocks, "decode run of %zu calls exceeds the %d blocks of the cross-attention pool",
+                 reqs.size(), pool->n_blocks);
+    pool_acquire(pool, ids, ns, hold.blk, hit);
+    int bx = 0;
+    for (size_t i = 0; i < reqs.size(); ++i) {
+      if ((rc = ensure_cross_kv(m, reqs[i]->enc, hold.blk[i], hit[i] != 0))) return rc;
+      for (int b = 0; b < reqs[i]->B; ++b)
+        for (int j = 0; j < kv_div; ++j) slot_host[bx++] = hold.blk[i] * pool->EB + b;
     }
   }
   GenDev gp;
@@ -518,6 +644,13 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   }
   FW_HIP(hipMemcpyAsync(g->prompt_dev, ptok.data(), ptok.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FW_HIP(hipMemcpyAsync(g->cur_tok, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  // (the cross-attention kernel divides the decode chunk by kv_div before it looks the slot up: one entry per ENCODER chunk)
+  {
+    std::vector<int> enc_slots((size_t)B);
+    for (int b = 0; b < B; ++b) enc_slots[b] = slot_host[(size_t)b * kv_div];
+    slot_host.swap(enc_slots);
+  }
+  FW_HIP(hipMemcpyAsync(g->slot_map, slot_host.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   FW_HIP(hipStreamSynchronize(st));   // the host buffers above are locals
 
   // ---- prompt forward (all but the last token): Bx rows, beam slot 0 of every chunk ----
@@ -660,13 +793,10 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   // random sampling (the sequential path's temperature fallback, transcribe.py:1433-1439): beam_size 1,
   // sampling_topk 0 (whole distribution), num_hypotheses = best_of independent samples per chunk
   const bool sampling = (K == 1 && o->sampling_topk != 1);
-  const int row_cap = std::max(dm->decode_batch, dm->max_batch) * dm->max_beam;
   if (sampling) {
     FW_CHECK_ARG(o->sampling_topk == 0, "sampling_topk must be 1 (greedy) or 0 (sample the whole distribution)");
     FW_CHECK_ARG(o->sampling_temperature > 0.f, "sampling_temperature must be positive");
-    FW_CHECK_ARG(o->num_hypotheses >= 1 && B * o->num_hypotheses <= row_cap,
-                 "batch x num_hypotheses = %d exceeds the %d decoder rows of this model", B * o->num_hypotheses,
-                 row_cap);
+    FW_CHECK_ARG(o->num_hypotheses >= 1, "num_hypotheses must be positive");
   } else {
     FW_CHECK_ARG(o->num_hypotheses >= 1 && o->num_hypotheses <= std::max(K, 1),
                  "num_hypotheses %d must be in [1, beam_size]", o->num_hypotheses);
@@ -707,10 +837,27 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
 
   DecodeGroup& grp = dm->grp;
   std::unique_lock<std::mutex> lk(grp.mu);
+  // fw_model_set_decode_batch rebuilds the workspaces and the second lane under grp.resizing: nothing is read from
+  // them (capacities, dm->lane1) and nothing is queued until it is done
+  while (grp.resizing) grp.cv.wait(lk);
+  {
+    // this call alone must fit a lane (rows and self-attention cache), so that a call that cannot is refused here,
+    // before it is merged with others whose run it would fail
+    const int64_t rows = sampling ? (int64_t)B * o->num_hypotheses : (int64_t)B * K;
+    const int64_t row_cap = (int64_t)lane_chunks_of(dm) * dm->max_beam;
+    const int ctx = run_ctx(c, o->max_length, P);
+    if (rows > row_cap || rows * ctx > planned_self_cap(dm)) {
+      lk.unlock();
+      set_error("this call needs %lld decoder rows x %d positions; a decode run of this model holds %lld rows and %lld "
+                "row-positions (batch x num_hypotheses / beam_size too large for max_length %d)",
+                (long long)rows, ctx, (long long)row_cap, (long long)planned_self_cap(dm), o->max_length);
+      return FW_EINVAL;
+    }
+  }
   grp.queue.push_back(&req);
   grp.last_arrival = std::chrono::steady_clock::now();
-  const int n_lanes = dm->lane1 ? 2 : 1;
   while (!req.done) {
+    const int n_lanes = dm->lane1 ? 2 : 1;     // (read under grp.mu: stable while a request is queued, see above)
     if (req.taken || grp.gathering || grp.active_runs >= std::min(n_lanes, grp.lanes_enabled.load())) {
       grp.cv.wait(lk);
       continue;
@@ -722,7 +869,7 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     // 120 ms; 0 = never) and skipped when no member encode is in flight.  One caller gathers at a time; with two lanes
     // the next one starts gathering as soon as this one has taken its requests and gone off to run them.
     grp.gathering = true;
-    const int cap = std::max(dm->decode_batch, dm->max_batch);
+    const int cap = lane_chunks_of(dm);
     int wait_ms = grp.merge_wait_ms.load();
     if (wait_ms < 0) wait_ms = std::min(120, std::max(5, (grp.enc_pass_us.load() * 5 / 4 + 999) / 1000));
     const int fill_pct = grp.merge_fill_pct.load();
@@ -742,12 +889,14 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     // chunks the self-attention cache holds at this call's context (mergeable calls share max_length and P)
     // ... and the rows above which the 4 x 4-tile decoder linears no longer fit the chip in one round of workgroups
     // (d x d: 20 column groups x 25 row groups of 64 rows = 500 of 512 workgroup slots)
-    int64_t run_cap = std::min<int64_t>(cap, self_chunk_capacity(dm, *first));
+    int64_t run_cap = std::min<int64_t>(cap, std::max<int64_t>(first->B, self_chunk_capacity(dm, *first)));
     if (!first->sampling)
       run_cap = std::min<int64_t>(run_cap, std::max<int64_t>(dm->max_batch, DEC_RUN_MAX_ROWS / std::max(1, first->o->beam_size)));
+    // (one pool block per call: a run never takes more calls than the pool has blocks)
+    const int max_calls = std::max(1, std::max(dm->decode_batch, dm->max_batch) / dm->max_batch);
     for (auto it = grp.queue.begin(); it != grp.queue.end();) {
       GenRequest* r = *it;
-      if (r == first || (mergeable(*first, *r) && chunks + r->B <= run_cap)) {
+      if (r == first || (mergeable(*first, *r) && chunks + r->B <= run_cap && (int)batch.size() < max_calls)) {
         batch.push_back(r);
         r->taken = true;
         chunks += r->B;
@@ -889,7 +1038,16 @@ int32_t fw_detect_language(fw_model* fm, const fw_tensor* enc_t, int32_t B, int3
   if ((rc = gen_workspace_ensure(m))) return rc;
   GenWorkspace* g = m->gen;
   hipStream_t st = m->dec_stream;
-  if ((rc = ensure_cross_kv(m, enc, 0))) return rc;
+  CrossPool* pool = pool_of(m);
+  PoolHold hold{pool, {}};
+  std::vector<int> slots(B);
+  {
+    std::vector<char> hit;
+    pool_acquire(pool, {enc->id}, {enc->B}, hold.blk, hit);
+    if ((rc = ensure_cross_kv(m, enc, hold.blk[0], hit[0] != 0))) return rc;
+    for (int b = 0; b < B; ++b) slots[b] = hold.blk[0] * pool->EB + b;
+  }
+  FW_HIP(hipMemcpyAsync(g->slot_map, slots.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
   GenDev gp;
   memset(&gp, 0, sizeof(gp));
   gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = 1; gp.V = c.n_vocab; gp.n_text_ctx = g->NT; gp.kv_div = 1;
@@ -1081,7 +1239,16 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
   if ((rc = gen_workspace_ensure(m))) return rc;
   GenWorkspace* g = m->gen;
   hipStream_t st = m->dec_stream;
-  if ((rc = ensure_cross_kv(m, enc, 0))) return rc;
+  CrossPool* pool = pool_of(m);
+  PoolHold hold{pool, {}};
+  std::vector<int> slots(B);
+  {
+    std::vector<char> hit;
+    pool_acquire(pool, {enc->id}, {enc->B}, hold.blk, hit);
+    if ((rc = ensure_cross_kv(m, enc, hold.blk[0], hit[0] != 0))) return rc;
+    for (int b = 0; b < B; ++b) slots[b] = hold.blk[0] * pool->EB + b;
+  }
+  const int kv_slot0 = slots[0];
 
   float *probs = nullptr, *stats = nullptr, *mat = nullptr, *tprob = nullptr;
   int *heads_dev = nullptr, *ntok_dev = nullptr, *nfr_dev = nullptr, *target_dev = nullptr;
@@ -1118,6 +1285,7 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
     he = hipMemcpyAsync(g->prompt_dev, ptok.data(), ptok.size() * sizeof(int), hipMemcpyHostToDevice, st);
   if (he == hipSuccess)
     he = hipMemcpyAsync(target_dev, target.data(), target.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(g->slot_map, slots.data(), B * sizeof(int), hipMemcpyHostToDevice, st);
   if (he == hipSuccess) he = hipMemsetAsync(g->kvidx2, 0, 2 * (size_t)g->R * g->NT, st);
   if (he == hipSuccess) he = hipMemsetAsync(g->d_step, 0, sizeof(int), st);
   if (he == hipSuccess) he = hipMemsetAsync(tprob, 0, (size_t)B * max_tok * sizeof(float), st);
@@ -1139,6 +1307,7 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
     s.need_logits = any_target;
     s.nospeech_rowmul = 0; s.beam_tail = false; s.done = g->zero_done;
     s.sel_heads_dev = heads_dev; s.sel_layer_off = layer_off.data(); s.probs = probs; s.n_sel_total = n_sel;
+    s.kv_slot0 = kv_slot0;
     s.n_tok = max_tok; s.tok_idx = pos;
     if ((rc = run_step(m, gp, s))) { cleanup(); return rc; }
     if (any_target)

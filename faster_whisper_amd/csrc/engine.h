@@ -94,8 +94,9 @@ struct Tensor {  // fw_tensor
   uint64_t id = 0;         // unique per encoder output (cross-K/V cache key)
 };
 
-struct GenWorkspace;  // decoder-side buffers (decoder.hip)
+struct GenWorkspace;  // decoder-side buffers of one decode lane (decoder.hip)
 struct GenRequest;    // one fw_generate call waiting to be decoded (decoder.hip)
+struct CrossPool;     // cross-attention K / V^T of the encoder outputs in flight, shared by the lanes (decoder.hip)
 
 // Decode group of a device: the worker replicas that share one decode workspace.  Concurrent fw_generate calls
 // with identical options are merged into ONE decode run (their rows share every weight byte streamed per step);
@@ -105,6 +106,7 @@ struct DecodeGroup {
   std::condition_variable cv;
   std::deque<GenRequest*> queue;
   bool gathering = false;         // a caller is collecting the requests of the next run (one at a time)
+  bool resizing = false;          // fw_model_set_decode_batch is rebuilding the workspaces / the second lane: callers wait
   int active_runs = 0;            // runs in flight (<= lanes of the group)
   bool lane_busy[2] = {false, false};
   std::atomic<int> lanes_enabled{2};   // fw_model_set_decode_lanes: runs allowed in flight (1 or 2)
@@ -176,7 +178,13 @@ struct Model {
   // measured +8 % (profiles/r03_two_groups_probe.txt).  Owned by the primary; never visible through the C ABI.
   Model* lane1 = nullptr;
   bool is_lane = false;
-  int decode_batch = 0;
+  // The cross-attention K / V^T cache is ONE pool per decode group (owned by the primary, borrowed by the second lane):
+  // blocks of max_batch chunk slots, one block per encoder output in flight, handed to whichever lane decodes the
+  // request — so both lanes can run full-size runs without each holding a cache of its own.
+  CrossPool* xpool = nullptr;
+  Model* pool_owner = nullptr;   // a lane: the primary whose pool it reads
+  int decode_batch = 0;          // chunk slots of the pool (= encoder chunks the group keeps in flight)
+  int lane_batch = 0;            // chunks ONE decode run (one lane's workspace) holds; 0: decode_batch
   int decode_self_ctx = 0;   // self-attention cache positions per row at full row capacity (0 = the text context)
   int dependents = 0;        // live models that use this one's weight blob or decode workspace (g_models_mu)
   bool free_deferred = false;   // fw_model_free was called while dependents > 0: freed with the last dependent
@@ -230,8 +238,16 @@ int run_encoder(Model* m, int B, half_t* out);
 uint64_t next_tensor_id();
 int gen_workspace_ensure(Model* dm);          // creates dm's decode workspace on first use (caller holds dm->dec_mu)
 void gen_workspace_free(Model* m);
-int64_t gen_workspace_bytes(const Model* m, int decode_batch, int self_ctx);   // self_ctx 0 = the text context
+// HBM of one lane's workspace for runs of up to lane_chunks chunks (self_ctx 0 = the text context) — without the
+// cross-attention pool, which is cross_pool_bytes(m, pool_chunks) once per group
+int64_t gen_workspace_bytes(const Model* m, int lane_chunks, int self_ctx);
+int64_t cross_pool_bytes(const Model* m, int pool_chunks);
+void cross_pool_free(Model* m);
 inline Model* decoder_of(Model* m) { return m->decoder ? m->decoder : m; }
+inline int lane_chunks_of(const Model* m) {
+  const int b = m->lane_batch > 0 ? m->lane_batch : m->decode_batch;
+  return b > m->max_batch ? b : m->max_batch;
+}
 
 }  // namespace fw
 

@@ -1063,6 +1063,7 @@ void fw_model_free(fw_model* fm) {
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   if (m->dec_stream) (void)hipStreamSynchronize(m->dec_stream);
   gen_workspace_free(m);
+  cross_pool_free(m);       // (a lane has none of its own: it reads the primary's)
   if (m->dec_stream) (void)hipStreamDestroy(m->dec_stream);
   for (half_t* p : m->enc_pool) (void)hipFree(p);
   m->enc_pool.clear();
@@ -1116,28 +1117,44 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   FW_CHECK_ARG(!m->decoder, "this model has joined another model's decoder");
   FW_CHECK_ARG(decode_batch >= 1, "decode_batch must be positive");
   {
-    // the workspaces (and the second lane's model) are rebuilt below: not while the group has work
+    // The workspaces, the pool and the second lane's model are rebuilt below: not while the group has work, and no
+    // fw_generate call may read capacities / dm->lane1 or queue a request until the rebuild is done (grp.resizing:
+    // callers wait on grp.cv).  fw_detect_language / fw_align hold dec_mu, which the rebuild takes.
     std::lock_guard<std::mutex> gl(m->grp.mu);
-    FW_CHECK_ARG(m->grp.active_runs == 0 && !m->grp.gathering && m->grp.queue.empty(),
+    FW_CHECK_ARG(m->grp.active_runs == 0 && !m->grp.gathering && m->grp.queue.empty() && !m->grp.resizing,
                  "decode runs are queued or in flight: set the decode batch before the first generate call or after the last one returned");
+    m->grp.resizing = true;
   }
+  struct Done {   // whatever the outcome: let the callers in again
+    DecodeGroup& g;
+    ~Done() {
+      { std::lock_guard<std::mutex> gl(g.mu); g.resizing = false; }
+      g.cv.notify_all();
+    }
+  } done{m->grp};
   std::lock_guard<std::mutex> lk(m->dec_mu);
   FW_HIP(hipSetDevice(m->device));
-  // Whole encoder batches, at least one, at most 2048 rows, in 70 % of the free HBM.  The cross-attention cache is
-  // fixed per chunk; the self-attention cache is rows x positions and a RUN lays it out for its own max_length
-  // (decoder.hip), so when the requested chunks do not fit with the whole text context per row, the positions per
-  // row are lowered first (down to 160: a run that asks for more then simply holds fewer rows) and only then the
-  // chunk count.
-  // Two lanes (two concurrent decode runs, engine.h: lane1) when the group is asked to hold at least four encoder
-  // batches; every lane is sized for the largest run there can be: the requested chunks, at most DEC_GROUP_RUN_ROWS
-  // rows (decoder.hip caps runs there).  The budget below is for all lanes together.
+  // Sizes, in 70 % of the free HBM:
+  //   pool   = the cross-attention K / V^T of `decode_batch` chunks (whole encoder batches, at least one): what the
+  //            workers of the group keep in flight, ONE copy whatever the number of lanes;
+  //   lanes  = two (two concurrent decode runs, engine.h: lane1) when the group holds at least four encoder batches,
+  //            each with a workspace for the largest run there can be: the pool's chunks, at most DEC_GROUP_RUN_ROWS rows
+  //            (decoder.hip caps runs there; one lane: 2048 rows).  The self-attention cache of a lane is rows x
+  //            positions and a RUN lays it out for its own max_length, so when the budget is short the positions per
+  //            row are lowered first (down to 160: a run that asks for more simply holds fewer rows), then the pool.
   int want = std::max(decode_batch, m->max_batch) / m->max_batch * m->max_batch;
   const int n_lanes = want >= 4 * m->max_batch ? 2 : 1;
-  while (want > m->max_batch && (int64_t)want * m->max_beam > (n_lanes == 2 ? DEC_GROUP_RUN_ROWS : 2048)) want -= m->max_batch;
+  const int max_rows = n_lanes == 2 ? DEC_GROUP_RUN_ROWS : 2048;
+  auto lane_of = [&](int pool_chunks) {
+    int lc = pool_chunks;
+    while (lc > m->max_batch && (int64_t)lc * m->max_beam > max_rows) lc -= m->max_batch;
+    return lc;
+  };
   size_t free_b = 0, total_b = 0;
   FW_HIP(hipMemGetInfo(&free_b, &total_b));
-  if (m->gen) free_b += (size_t)gen_workspace_bytes(m, m->decode_batch, m->decode_self_ctx);
-  if (m->lane1 && m->lane1->gen) free_b += (size_t)gen_workspace_bytes(m->lane1, m->lane1->decode_batch, m->lane1->decode_self_ctx);
+  if (m->gen) free_b += (size_t)gen_workspace_bytes(m, lane_chunks_of(m), m->decode_self_ctx);
+  if (m->lane1 && m->lane1->gen) free_b += (size_t)gen_workspace_bytes(m->lane1, lane_chunks_of(m->lane1), m->lane1->decode_self_ctx);
+  if (m->xpool) free_b += (size_t)cross_pool_bytes(m, std::max(m->decode_batch, m->max_batch));
   const int64_t budget = (int64_t)(0.7 * (double)free_b);
   const int NT = m->cfg.n_text_ctx;
   const int ctx_steps[] = {NT, 320, 224, 160};
@@ -1146,28 +1163,35 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
     bool fits = false;
     for (int cs : ctx_steps) {
       if (cs > NT) continue;
-      if (n_lanes * gen_workspace_bytes(m, want, cs) <= budget) { self_ctx = cs; fits = true; break; }
+      if (cross_pool_bytes(m, want) + n_lanes * gen_workspace_bytes(m, lane_of(want), cs) <= budget) { self_ctx = cs; fits = true; break; }
     }
     if (fits || want <= m->max_batch) break;
     want -= m->max_batch;
   }
+  const int lane_batch = lane_of(want);
   const bool lanes_ok = (n_lanes == 2) == (m->lane1 != nullptr);
-  if (m->gen && lanes_ok && want == m->decode_batch && self_ctx == m->decode_self_ctx) return FW_OK;
+  if (m->gen && m->xpool && lanes_ok && want == m->decode_batch && lane_batch == lane_chunks_of(m) &&
+      self_ctx == m->decode_self_ctx)
+    return FW_OK;
   if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
   gen_workspace_free(m);
   if (m->lane1) {
     fw_model_free(static_cast<fw_model*>(m->lane1->self));
     m->lane1 = nullptr;
   }
+  cross_pool_free(m);
   m->decode_batch = want;
+  m->lane_batch = lane_batch;
   m->decode_self_ctx = self_ctx;
-  int rc = gen_workspace_ensure(m);
+  int rc = gen_workspace_ensure(m);     // (creates the pool too)
   if (rc) return rc;
   if (n_lanes == 2) {
     fw_model* l = nullptr;
     if ((rc = model_from_blob(m->blob, m->blob_bytes, false, m->device, m->max_batch, m->max_beam, &l, true))) return rc;
     l->impl.decode_batch = want;
+    l->impl.lane_batch = lane_batch;
     l->impl.decode_self_ctx = self_ctx;
+    l->impl.pool_owner = m;
     l->impl.prof_on = m->prof_on;
     if ((rc = gen_workspace_ensure(&l->impl))) { fw_model_free(l); return rc; }
     m->lane1 = &l->impl;
@@ -1198,6 +1222,11 @@ int32_t fw_model_decode_batch(const fw_model* fm) {
   return std::max(m->decode_batch, m->max_batch);
 }
 
+int32_t fw_model_run_capacity(const fw_model* fm) {
+  if (!fm) return 0;
+  return lane_chunks_of(fm->impl.decoder ? fm->impl.decoder : &fm->impl);
+}
+
 int32_t fw_model_decode_stats(const fw_model* fm, int64_t* runs, int64_t* requests, int64_t* chunks,
                               int32_t* max_run_chunks) {
   FW_CHECK_ARG(fm, "null model");
@@ -1221,6 +1250,7 @@ int32_t fw_model_join_decoder(fw_model* fm, fw_model* decoder) {
   FW_HIP(hipSetDevice(m->device));
   if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
   gen_workspace_free(m);
+  cross_pool_free(m);
   {
     std::lock_guard<std::mutex> lk2(g_models_mu);   // the primary outlives its workers (fw_model_free defers)
     d->dependents += 1;
@@ -1737,6 +1767,8 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
   cleanup();
   return rc;
 }
+
+int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
 
 int32_t fw_test_dec_logits(fw_model* fm, const float* x, int32_t R, float* out) {
   FW_CHECK_ARG(fm && x && out && R >= 1, "bad argument");

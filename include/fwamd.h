@@ -47,7 +47,10 @@ extern "C" {
 #define FW_ENOMEM (-3)   /* device or host allocation failed          */
 #define FW_ERUNTIME (-4) /* kernel launch / internal error            */
 
-#define FW_ABI_VERSION 1
+/* 2: fw_model_set_encoder_cus / fw_model_encoder_cus removed, fw_model_set_merge_wait, fw_model_set_decode_lanes and
+ *    fw_model_run_capacity added, test / bench hooks moved to fwamd_test.h; the cross-attention cache of a decode group
+ *    is one pool shared by its lanes (fw_model_decode_batch = chunks of the pool, fw_model_run_capacity = chunks of one run) */
+#define FW_ABI_VERSION 2
 
 /* compute types (the reference passes the CTranslate2 strings, transcribe.py:626) */
 #define FW_COMPUTE_FLOAT16 0      /* "float16" / "default" on GPU */
@@ -155,13 +158,17 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
 /* Decode groups — what CTranslate2's replica pool (inter_threads; transcribe.py:645-657, :689-698) becomes on a
  * GPU with 288 GB of HBM.  A decode step streams every decoder weight once whatever the number of rows, so the
  * worker replicas of a device share ONE decode workspace instead of decoding side by side:
- *   fw_model_set_decode_batch(primary, n_workers * max_batch)  sizes the primary's decode workspace for that many
- *       chunks (rounded down to whole encoder batches, 2048 rows and what fits in HBM; fw_model_decode_batch reads it
- *       back).  The self-attention cache is rows x positions and every run lays it out for its own max_length, so a
- *       run of calls with a short max_length holds more chunks than one that asks for the whole text context.  From
- *       four encoder batches on, the group decodes on TWO lanes (two workspaces, two streams, the budget covers both):
- *       two decode runs are in flight at once, the HBM-bound cross-attention of one beside the linears of the other;
- *       setup-time call: FW_EINVAL while the group has decode runs queued or in flight;
+ *   fw_model_set_decode_batch(primary, n_workers * max_batch)  sizes the group for that many chunks in flight: the
+ *       cross-attention K / V^T pool holds them (rounded down to whole encoder batches and to what fits in 70 % of the free
+ *       HBM; fw_model_decode_batch reads the pool's chunk count back), ONE copy whatever the number of lanes: an encoder
+ *       output's block of the pool is handed to whichever lane decodes it.  A decode RUN holds at most
+ *       fw_model_run_capacity chunks: 2048 rows with one lane, 1600 rows per lane with two (from four encoder batches on
+ *       the group decodes on TWO lanes — two run workspaces, two streams: two decode runs are in flight at once, the
+ *       HBM-bound cross-attention of one beside the linears of the other).  The self-attention cache of a lane is rows x
+ *       positions and every run lays it out for its own max_length, so a run of calls with a short max_length holds more
+ *       chunks than one that asks for the whole text context (positions per row are lowered, down to 160, before the
+ *       pool is).  Setup-time call: FW_EINVAL while the group has decode runs queued or in flight; fw_generate calls that
+ *       arrive during the rebuild wait for it;
  *   fw_model_join_decoder(worker, primary)  frees the worker's own decode workspace and routes its fw_generate /
  *       fw_detect_language / fw_align calls to the primary's.
  * fw_generate calls with identical options that arrive from different host threads while a decode run is in
@@ -169,6 +176,8 @@ int32_t fw_model_create_from_blob_dev(const fw_config* cfg, const void* blob_dev
  * get alone.  Encoders keep running per worker on their own streams and overlap with the running decode. */
 int32_t fw_model_set_decode_batch(fw_model* m, int32_t decode_batch);
 int32_t fw_model_decode_batch(const fw_model* m);
+/* chunks one decode run of the group can hold (<= fw_model_decode_batch) */
+int32_t fw_model_run_capacity(const fw_model* m);
 int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
 /* How long, and for how much, the leader of a decode run waits for the requests of workers that are still encoding
  * (latency of the waiting call against rows per run).  wait_ms: -1 = one measured encoder pass after the last arrival,

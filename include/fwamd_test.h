@@ -53,6 +53,10 @@ int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const flo
  * B chunks x H heads x T positions on device-resident pseudo-random operands; variant is reserved (pass 0) */
 int32_t fw_bench_attention(fw_model* m, int32_t B, int32_t H, int32_t T, int32_t variant, int32_t iters, float* ms_out);
 
+/* rows from which a decode run's per-layer linears take the GEMM-shaped kernel (dec_kernels.hip: DEC_BIG_MIN_ROWS);
+ * bench.py prices the decoder linears against the MFMA roof from this row count on, against HBM below */
+int32_t fw_dec_big_min_rows(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the Python binding table covers the header
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.fw_abi_version() == 1
+    assert lib.fw_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -14,11 +14,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-WORKER = r'''
+SEAM = r'''
 import json, os, struct, sys, threading
 import numpy as np
-sys.path.insert(0, os.environ["FW_ROOT"])
-import bench
+
+DIST_BACKEND = "gloo"
 
 
 class Result:
@@ -98,8 +98,13 @@ def factory(args, cfg, rank, world, local_rank):
     assert total == raw.shape[0], (total, raw.shape)
     assert t.data_ptr() != 0 and t.numel() == total
     return FakeBackend(cfg, args.workers, (t.data_ptr(), t.numel())), None
+'''
 
-
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FW_ROOT"])
+import bench
+''' + SEAM + r'''
 out = bench.main(["--gpus", os.environ["WORLD_SIZE"], "--model", "micro", "--batch", "4", "--beam", "5", "--steps", "6",
                   "--warmup", "1", "--workers", "2", "--new-tokens", "12", "--pipeline-chunks", "11", "--sharded-chunks", "11",
                   "--no-cpu-baseline"], backend_factory=factory, dist_backend="gloo")
@@ -175,3 +180,33 @@ def test_bench_one_rank_takes_the_multi_rank_flow(tmp_path):
     assert "error" not in sh and "error" not in serial, (sh, serial)
     assert sh["segments"] == serial["segments"] == 11 and sh["tokens"] == serial["tokens"] == 11 * 12
     assert sh["digest"] == serial["digest"]
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 --steps 4` with NO rank environment (the form the driver uses for N = 1): bench.py itself
+    starts two ranks under torch.distributed.run (bench.relaunch) and rank 0 prints ONE line with n_gpus: 2.  The ranks
+    are fresh `python bench.py` processes; FWAMD_BENCH_SEAM hands them the scripted backend and the gloo backend."""
+    seam = tmp_path / "seam.py"
+    seam.write_text(SEAM)
+    env = dict(os.environ, FWAMD_BENCH_SEAM=str(seam), OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FWAMD_DIST_AT_WORLD_1"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--model", "micro", "--batch", "4", "--beam", "5", "--workers", "2", "--new-tokens", "12",
+                        "--pipeline-chunks", "11", "--sharded-chunks", "11", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["config"]["global_batch"] == 8 and j["value"] > 0
+    assert j["sharded_recording"]["segments"] == 11
+
+
+def test_bench_refuses_a_world_that_is_not_gpus(tmp_path):
+    """--gpus must be the job size: a launcher that started a different number of ranks is an error, not a line"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "refusing" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -13,7 +13,14 @@ of CPU.  What is compared, per configuration:
     (conftest.check_hypothesis), no-speech probability;
   * detect_language probabilities; align: token probabilities, word-boundary frames <= 2;
   * merged decode runs (test_merged_run_*): every caller bit-identical to its solo call, the oracle on the first and
-    the last chunk of the merged run.
+    the last chunk of the merged run — at 640 rows (8 workers, 24 steps: the 2 x 2-tile register-streaming linears) and at
+    **1 095 rows, 100 steps, two decode lanes** (14 workers: what bench.py executes — the runs go through
+    dec_gemm_big_kernel, DEC_BIG_MIN_ROWS = 1 024, the 160-position self-attention layout, the vocabulary projection
+    with 14 row groups);
+  * the vocabulary projection alone at 1 360 and 1 600 rows (the row counts of bench.py's runs) against fp64;
+  * one solo run of 224 steps (the cap case of bench.py) scored by the teacher-forced oracle;
+  * **literal** greedy-id equality over 64 steps on PEAKED weights (weights.make_peaked): every id
+    the engine emits is the oracle's arg-max, with the oracle's top-1 / top-2 margin asserted above the fp16 noise.
 
 Tolerances.  The north-star figure is NORTH_STAR = 1e-3 (BASELINE.json: "segment timestamps/logprobs within 1e-3 at
 beam_size=5") and it is what every quantity is asserted at, except the entries of EXCEPTIONS below, each with the
@@ -101,7 +108,42 @@ def _chunks():
     return out
 
 
-def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
+def _logits_projection(model, cfg, w, i8, rows=(1360, 1600)):
+    """the vocabulary projection at the row counts of bench.py's merged runs (two-lane runs hold 272 chunks = 1 360 rows,
+    one-lane runs up to 320 = 1 600): 17 / 20 row groups x 406 column groups of dec_gemm_wave_kernel, final LayerNorm
+    folded (fp16) or fused into the row quantiser (int8).  Reference: fp64 on a column sample that covers the first
+    and the last (ragged: 51 866 = 3 241 x 16 + 10) column tile; every row."""
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    E = w["dec.tok_emb"].astype(np.float64)
+    g, b = w["dec.ln.g"].astype(np.float64), w["dec.ln.b"].astype(np.float64)
+    rng = np.random.default_rng(77)
+    cols = np.unique(np.concatenate([np.arange(0, 48), np.arange(cfg.n_vocab - 48, cfg.n_vocab),
+                                     rng.integers(0, cfg.n_vocab, 4000)]))
+    worst = 0.0
+    for R in rows:
+        x = (rng.standard_normal((R, cfg.d_model)) * 2 + 0.5).astype(np.float16).astype(np.float32)
+        out = np.empty((R, cfg.n_vocab), np.float32)
+        _lib.check(lib.fw_test_dec_logits(model._replicas[0].handle, _lib.ptr(x), R, _lib.ptr(out)))
+        xd = x.astype(np.float64)
+        xn = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-5) * g + b
+        if i8:     # the engine quantises the LayerNorm'ed rows (fp16, per-row absmax) and the tied embedding (per row)
+            xn = xn.astype(np.float16).astype(np.float64)
+            sx = np.abs(xn).max(1, keepdims=True) / 127.0
+            xn = np.rint(xn / sx) * sx
+            sw = np.abs(E[cols]).max(1, keepdims=True) / 127.0
+            Ec = np.rint(E[cols] / sw) * sw
+        else:
+            Ec = E[cols]
+        ref = xn @ Ec.T
+        err = float(np.abs(out[:, cols] - ref).max() / max(1.0, np.abs(ref).max()))
+        assert np.isfinite(out).all()
+        print(f"[{cfg.name}] vocabulary projection R={R}: rel err {err:.2e} on {len(cols)} sampled columns x every row")
+        worst = max(worst, err)
+    return worst
+
+
+def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48, long_steps=0, logits_rows=()):
     from faster_whisper_amd import Whisper
     from faster_whisper_amd.backend import StorageView, language_token_strings
     i8 = compute_type == "int8_float16"
@@ -196,6 +238,23 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
         jd = int(np.abs(gj - rj).max())
         print(f"{tag} chunk {b}: align token prob err {pe:.2e}, max word-boundary diff {jd} frames")
         expect(pe < tol["align"] and jd <= 2, f"align chunk {b}: prob err {pe:.2e}, boundary diff {jd}")
+    # ---- the vocabulary projection at the row counts of bench.py's merged runs ----
+    if logits_rows:
+        e = _logits_projection(model, cfg, w, i8, logits_rows)
+        expect(e < (2e-2 if i8 else 3e-3), f"vocabulary projection at {logits_rows} rows: {e:.2e}")
+
+    # ---- one solo run at the cap length (bench.py's cap_case: 224 new tokens), scored by the teacher-forced oracle ----
+    if long_steps:
+        kw = dict(beam_size=5, patience=1.0, length_penalty=1.0, max_length=len(prompt) + long_steps,
+                  suppress_tokens=sup, min_new_tokens=long_steps)
+        gl5 = model.generate(enc, [prompt] * B, return_scores=True, **kw)
+        assert all(len(g.sequences_ids[0]) == long_steps and np.isfinite(g.scores[0]) for g in gl5)
+        b = SUBSET[1]
+        sf = forced_score(oracle, sub[1], prompt, gl5[b].sequences_ids[0], kw)
+        dlt = abs(gl5[b].scores[0] - sf) / max(1.0, abs(sf))
+        print(f"{tag} chunk {b}: {long_steps}-step beam-5 hypothesis, engine score {gl5[b].scores[0]:.5f} vs the oracle's "
+              f"score of the same ids {sf:.5f} (rel {dlt:.2e})")
+        expect(dlt < tol["beam"], f"{long_steps}-step run chunk {b}: {gl5[b].scores[0]} vs {sf}")
     assert not fails, fails
 
 
@@ -206,7 +265,8 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48):
 # vocabulary projection and the per-run self-attention cache geometry, none of which a 16-chunk call reaches.
 # Reference behaviour: one generate() per batch, transcribe.py:222-246; CTranslate2 replicas decode side by side.
 # ---------------------------------------------------------------------------------------------------------------
-def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7, 15))):
+def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7, 15)), oracle_search=True,
+            min_rows=0):
     import threading
     import time
     from faster_whisper_amd import Whisper
@@ -269,6 +329,7 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
     print(f"{tag} {workers} concurrent calls ({n_chunks} chunks) -> {st['runs'] - st0['runs'] - 2} decode run(s), "
           f"largest run {st['max_run_chunks']} chunks = {5 * st['max_run_chunks']} rows")
     assert st["max_run_chunks"] == n_chunks           # ONE run carried every caller
+    assert 5 * n_chunks >= min_rows, (n_chunks, min_rows)
     for i in range(workers):
         for j, (a, b) in enumerate(zip(out[i], solo[i])):
             assert a.sequences_ids == b.sequences_ids, (tag, i, j)
@@ -280,6 +341,15 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
     for (i, j) in oracle_chunks:
         j = min(j, len(batches[i]) - 1)
         e1 = model.encode_pcm([batches[i][j]]).to_numpy()
+        if not oracle_search:
+            # long runs: the oracle scores the engine's own hypothesis (teacher forcing: cost linear in the length); its
+            # own beam search over the same length is what test_large_v3_* / the 24-step merged tests run
+            sf = forced_score(oracle, e1[0], prompt, out[i][j].sequences_ids[0], okw)
+            dlt = abs(out[i][j].scores[0] - sf) / max(1.0, abs(sf))
+            print(f"{tag} call {i} chunk {j}: {steps} steps, engine score {out[i][j].scores[0]:.5f} vs the oracle's score "
+                  f"of the same ids {sf:.5f} (rel {dlt:.2e})")
+            assert dlt < tb, (tag, i, j, out[i][j].scores[0], sf)
+            continue
         ref = oracle.generate(e1, [prompt], **okw)[0]
         check_hypothesis(oracle, e1[0], prompt, out[i][j], ref, okw, tol=tb, gap=6e-2 if i8 else 2e-2,
                          boundary=2 * tb, what=f"{tag} call {i} chunk {j}")
@@ -291,9 +361,12 @@ def _merged(cfg, w, compute_type, workers=8, steps=24, oracle_chunks=((0, 0), (7
 # The tests, in the order they run: those that share an oracle (same geometry, same compute type) follow one another,
 # so that `_oracle` builds each of the three oracles once and holds one at a time.
 # ---------------------------------------------------------------------------------------------------------------
+BENCH_ROWS = 1024     # dec_kernels.hip DEC_BIG_MIN_ROWS: runs of at least this many rows take dec_gemm_big_kernel
+
+
 def test_large_v3_float16(lv3):
     cfg, w = lv3
-    _run(cfg, w, "float16")
+    _run(cfg, w, "float16", long_steps=224, logits_rows=(1360, 1600))
 
 
 def test_merged_run_large_v3_float16(lv3):
@@ -301,14 +374,74 @@ def test_merged_run_large_v3_float16(lv3):
     _merged(cfg, w, "float16")
 
 
+def test_merged_run_bench_geometry_large_v3_float16(lv3):
+    """what bench.py executes: 14 workers x 16 chunks (one batch of 11) = 219 chunks x beam 5 = 1 095 rows in ONE decode
+    run, two decode lanes enabled (both kept busy while the callers queue up), max_length = prompt + 100"""
+    cfg, w = lv3
+    _merged(cfg, w, "float16", workers=14, steps=100, oracle_chunks=((0, 0), (13, 15)), oracle_search=False,
+            min_rows=BENCH_ROWS)
+
+
+def test_peaked_greedy_literal_ids_large_v3_float16(lv3):
+    """BASELINE.json north star: "token ids bit-exact at beam_size=1 greedy".  On the peaked variant of the weights the
+    claim is tested literally: 64 greedy steps on 16 chunks; the oracle is teacher-forced along the engine's ids and
+    EVERY id must be its arg-max (gap exactly 0), with the oracle's top-1 / top-2 margin along that path asserted to
+    be at least 10 x the fp16 noise margin the other tests allow (so the equality is not a coincidence of ties)."""
+    from conftest import greedy_gaps
+    from faster_whisper_amd import Whisper
+    from faster_whisper_amd.weights import make_peaked, peaked_candidates
+    cfg, w = lv3
+    wp = make_peaked(cfg, w, seed=1234)
+    model = Whisper(f"synthetic:{cfg.name}", device="cuda", files={"config": cfg, "weights": wp},
+                    compute_type="float16", max_batch_size=B, max_beam_size=5)
+    oracle = _oracle(cfg, w, False)
+    import torch
+    keep = oracle.w["dec.pos"]
+    oracle.w["dec.pos"] = torch.from_numpy(wp["dec.pos"].astype(np.float32))      # the only tensor that differs
+    try:
+        chunks = _chunks()
+        enc = model.encode_pcm(chunks)
+        got = enc.to_numpy()
+        prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+        sup = [cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe]
+        steps = 64
+        kw = dict(beam_size=1, max_length=len(prompt) + steps, length_penalty=0.0, suppress_tokens=sup)
+        g1 = model.generate(enc, [prompt] * B, return_scores=True, **kw)
+        cand = peaked_candidates(cfg, 1234)
+        for b in SUBSET:
+            ids = g1[b].sequences_ids[0]
+            assert len(ids) == steps
+            k2 = {k: v for k, v in kw.items() if k != "beam_size"}
+            r = oracle.generate(got[b][None], [prompt], beam_size=1, force_tokens=[ids], **k2)[0]
+            assert r.sequences_ids[0] == ids
+            gaps, margins = np.array(r.forced_gaps), np.array(r.margins[:steps])
+            n_cand = sum(int(t in cand[len(prompt) - 1 + i]) for i, t in enumerate(ids))
+            print(f"[{cfg.name} float16 peaked] chunk {b}: {steps} greedy ids, {int((gaps == 0).sum())} are the oracle's "
+                  f"arg-max; oracle margins min {margins.min():.3f} median {np.median(margins):.2f}; {n_cand} of the ids "
+                  f"are one of the two peaked candidates; score {g1[b].scores[0]:.5f} vs {r.scores[0]:.5f}")
+            assert margins.min() >= 0.2, ("the peaked weights are not peaked enough at some step", margins.min())
+            assert (gaps == 0).all(), (b, gaps)                # literal id equality, step by step
+            assert abs(g1[b].scores[0] - r.scores[0]) / steps < tolerance(cfg.name, "float16", "tf")
+        # the chunks the oracle was not run on: same audio statistics, they must at least agree on peaked steps
+        assert all(len(g.sequences_ids[0]) == steps for g in g1)
+    finally:
+        oracle.w["dec.pos"] = keep
+
+
 def test_large_v3_int8_float16(lv3):
     cfg, w = lv3
-    _run(cfg, w, "int8_float16", tf_steps=8, beam_steps=48)
+    _run(cfg, w, "int8_float16", tf_steps=8, beam_steps=48, logits_rows=(1360,))
 
 
 def test_merged_run_large_v3_int8_float16(lv3):
     cfg, w = lv3
     _merged(cfg, w, "int8_float16", oracle_chunks=((7, 15),))
+
+
+def test_merged_run_bench_geometry_large_v3_int8_float16(lv3):
+    cfg, w = lv3
+    _merged(cfg, w, "int8_float16", workers=14, steps=100, oracle_chunks=((13, 15),), oracle_search=False,
+            min_rows=BENCH_ROWS)
 
 
 def test_distil_large_v3_float16(lv3):
