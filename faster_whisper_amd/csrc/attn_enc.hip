@@ -17,6 +17,12 @@
 //    V^T tile: rows padded to 136 bytes (conflict-free ds_read_b64).
 //  * register-staged double buffering: next tile's global loads are issued before
 //    the MFMA/softmax block, written to LDS after it; one barrier per 64-key tile.
+//  * XCD-aware 1-D grid: the 12 query-tile workgroups of a (chunk, head) all stream the same K / V^T (384 KB); the
+//    hardware places block b on XCD b % 8, so with the query tile as the fastest grid index they were spread over all
+//    eight L2s and every L2 fetched the pair's K / V^T from HBM (measured round 3: 1 070 MB fetched per launch against
+//    246 MB algorithmic).  Now the (chunk, head) pairs are dealt round-robin to the XCDs and the query tiles of a pair
+//    are consecutive blocks OF ONE XCD: ~8 pairs are resident per XCD at a time (3 MB of K / V^T in a 4 MB L2), the
+//    first workgroup of a pair misses and the other eleven hit.
 //  * online softmax in fp32 with exp2.  The vector pipe, not the matrix pipe, is what bounds this kernel (per 64-key
 //    tile and wave: 16 MFMAs = 512 matrix cycles against, originally, ~210 vector instructions), so the softmax is
 //    written for the fewest vector instructions: log2 e / 8 is folded into the Q fragment once (no per-score scaling),
@@ -33,13 +39,19 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
                                                        int64_t ld, int64_t qk_bstride,
                                                        const half_t* __restrict__ vt, int64_t ldvt,
                                                        int64_t vt_bstride, half_t* __restrict__ out, int64_t ldo,
-                                                       int64_t o_bstride, int T) {
+                                                       int64_t o_bstride, int T, int H, int n_pairs, int n_qt,
+                                                       int order) {
   __shared__ __attribute__((aligned(16))) half_t sK[2][AE_KV * 64];
   __shared__ __attribute__((aligned(16))) half_t sV[2][64 * AE_VSTRIDE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AE_Q;
+  // block -> (pair, query tile): XCD x = block % 8 owns the pairs x, x + 8, ...; its blocks walk them tile by tile
+  // (order 1 = the round-3 mapping, query tile fastest over ALL XCDs: kept for the A/B of profiles/attn_bench.py)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int pair = order ? (int)blockIdx.x / n_qt : (idx / n_qt) * 8 + xcd;
+  if (pair >= n_pairs) return;               // (whole workgroups: before any barrier)
+  const int b = pair / H, h = pair - b * H, q0 = (order ? (int)blockIdx.x % n_qt : idx % n_qt) * AE_Q;
 
   const half_t* qb = q + (size_t)b * qk_bstride + h * 64;
   const half_t* kb = k + (size_t)b * qk_bstride + h * 64;
@@ -197,9 +209,10 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
 namespace fwk {
 void launch_attn_enc(hipStream_t st, const half_t* q, const half_t* k, int64_t ld, int64_t qk_bstride,
                      const half_t* vt, int64_t ldvt, int64_t vt_bstride, half_t* out, int64_t ldo,
-                     int64_t o_bstride, int B, int H, int T) {
-  dim3 grid((T + AE_Q - 1) / AE_Q, H, B);
+                     int64_t o_bstride, int B, int H, int T, int order) {
+  const int n_qt = (T + AE_Q - 1) / AE_Q, n_pairs = B * H;
+  const int grid = ((n_pairs + 7) / 8) * 8 * n_qt;
   // (132 registers: 3 waves per SIMD.  Forcing 4 with __launch_bounds__(256, 4) spills and measured 6 % slower.)
-  attn_enc_kernel<<<grid, 256, 0, st>>>(q, k, ld, qk_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, T);
+  attn_enc_kernel<<<grid, 256, 0, st>>>(q, k, ld, qk_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, T, H, n_pairs, n_qt, order);
 }
 }  // namespace fwk

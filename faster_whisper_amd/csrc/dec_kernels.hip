@@ -1648,12 +1648,14 @@ static void wave_go(hipStream_t st, const void* xf, const float* x_scale, const 
 int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_scale, const void* Wf,
                       const float* w_scale, const float* s1, const float* cf, float* out, int ldo, int R, int N, int K) {
   if (K % (i8 ? 64 : 32) != 0 || R < 1) return -1;
-  if (i8 ? (!x_scale || !w_scale) : (!s1 || !cf)) return -1;
+  if (i8 ? (!x_scale || !w_scale) : ((s1 == nullptr) != (cf == nullptr))) return -1;
   const int n_rt = (R + 15) / 16;
+  // fp16 with s1 == cf == null: xf already holds fp16(LayerNorm(x)) and Wf the tied embedding itself (no bias)
 #define WG(RT)                                                                                   \
   do {                                                                                           \
     if (i8) wave_go<true, false, RT>(st, xf, x_scale, Wf, w_scale, s1, cf, out, ldo, R, N, K);   \
-    else wave_go<false, true, RT>(st, xf, x_scale, Wf, w_scale, s1, cf, out, ldo, R, N, K);      \
+    else if (s1) wave_go<false, true, RT>(st, xf, x_scale, Wf, w_scale, s1, cf, out, ldo, R, N, K); \
+    else wave_go<false, false, RT>(st, xf, x_scale, Wf, w_scale, s1, cf, out, ldo, R, N, K);     \
   } while (0)
   if (n_rt == 1) WG(1);
   else if (n_rt == 2) WG(2);

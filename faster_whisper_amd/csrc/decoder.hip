@@ -87,6 +87,7 @@ struct GenWorkspace {
   unsigned long long* sup_bits = nullptr;   // suppress list, one bit per token id
   int* zero_done = nullptr;              // [R] zeros (kernels that take a `done` pointer outside generate)
   half_t *x_frag = nullptr, *att_frag = nullptr, *ffn_frag = nullptr;   // fragment-major GEMM inputs (fp16)
+  half_t* xn_frag = nullptr;             // fp16(LayerNorm(x)), fragment-major (explicit-LayerNorm order, Model::ln_unfold)
   int8_t* xq = nullptr;                  // int8_float16: quantised linear input, fragment-major [R16][4d]
   float* xs = nullptr;                   //               per-row de-quantisation scale [R]
   int8_t* ekq = nullptr;                 // int8_float16: one encoder output quantised for the cross-K/V projection
@@ -261,7 +262,8 @@ static int gen_workspace_build(Model* m) {
     A(g->ekq, (size_t)g->EB * c.n_audio_ctx * d);
     A(g->eks, (size_t)g->EB * c.n_audio_ctx);
   } else {
-    A(g->x_frag, R16 * d); A(g->att_frag, R16 * d); A(g->ffn_frag, R16 * 4 * d);
+    A(g->x_frag, R16 * d); A(g->att_frag, R16 * d); A(g->ffn_frag, R16 * 4 * d); A(g->xn_frag, R16 * d);
+    FW_HIP(hipMemset(g->xn_frag, 0, R16 * d * sizeof(half_t)));
     FW_HIP(hipMemset(g->x_frag, 0, R16 * d * sizeof(half_t)));
     FW_HIP(hipMemset(g->att_frag, 0, R16 * d * sizeof(half_t)));
     FW_HIP(hipMemset(g->ffn_frag, 0, R16 * 4 * d * sizeof(half_t)));
@@ -295,7 +297,7 @@ void gen_workspace_free(Model* m) {
   void* ptrs[] = {g->slot_map, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_bits,
-                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag};
+                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag, g->xn_frag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -402,6 +404,14 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
                                      L.K, act);
   };
   const int frag = i8 ? 0 : 1;
+  // fp16, explicit-LayerNorm order (Model::ln_unfold == 2): the LayerNorm is its own kernel, its fp16 output (fragment-
+  // major) feeds the plain weight — the rounding points of an fp16 LayerNorm followed by an fp16 GEMM
+  const bool unf = !i8 && m->ln_unfold >= 2;
+  auto lin_u = [&](const LNW& ln, const LinearW& L, half_t* outp, half_t* outp_frag, int act) -> int {
+    fwk::launch_layernorm(st, g->x, ln.g, ln.b, g->xn_frag, rows, d, 1);
+    return fwd::launch_dec_gemm_frag(st, g->xn_frag, L.w, L.b, nullptr, nullptr, nullptr, L.N, outp, L.N, outp_frag, rows,
+                                     L.N, L.K, act);
+  };
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
     // the run's own cache geometry: [layer][cache_rows slots][H][ctx][64]
@@ -412,6 +422,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
+      else if (unf) DG(lin_u(L.ln1, L.qkv_p, g->qkv, nullptr, 0));
       else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
     }
     {
@@ -426,7 +437,8 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
         DG(lin_q(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
       } else {
         DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0));
-        DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0));
+        if (unf) DG(lin_u(L.ln2, L.cq_p, g->qc, nullptr, 0));
+        else DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0));
       }
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
@@ -448,6 +460,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
+      else if (unf) DG(lin_u(L.ln3, L.ffn1_p, nullptr, g->ffn_frag, 1));
       else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
     }
     {
@@ -461,6 +474,10 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     if (i8) {
       fwk::launch_quant_rows(st, g->x, d, m->dec_ln.g, m->dec_ln.b, g->xq, g->xs, rows, d, 1);
       DG(fwd::launch_dec_logits(st, true, g->xq, g->xs, m->logits.wq, m->logits.wscale, nullptr, nullptr, g->logits,
+                                c.n_vocab, rows, c.n_vocab, d));
+    } else if (m->ln_unfold >= 1) {
+      fwk::launch_layernorm(st, g->x, m->dec_ln.g, m->dec_ln.b, g->xn_frag, rows, d, 1);
+      DG(fwd::launch_dec_logits(st, false, g->xn_frag, nullptr, m->logits_p.w, nullptr, nullptr, nullptr, g->logits,
                                 c.n_vocab, rows, c.n_vocab, d));
     } else {
       DG(fwd::launch_dec_logits(st, false, g->x_frag, nullptr, m->logits.w, nullptr, m->logits.s1, m->logits.cf,

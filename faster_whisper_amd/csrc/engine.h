@@ -73,8 +73,9 @@ struct LinearW {           // y = x W^T + b ; W [N][K] fp16 (or int8 + per-row s
 struct LNW { const half_t* g = nullptr; const half_t* b = nullptr; };
 
 struct EncLayerW { LNW ln1, ln2; LinearW qk, v, out, ffn1, ffn2; };
-// fp16: qkv, cq, ffn1 are LN-folded (ln1/2/3 unused); int8_float16: explicit LayerNorms feeding the quantiser
-struct DecLayerW { LNW ln1, ln2, ln3; LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; };
+// fp16: qkv, cq, ffn1 are LN-folded; the blob also carries the plain weights (qkv_p, cq_p, ffn1_p) and ln1/2/3 for the
+// explicit-LayerNorm evaluation (Model::ln_unfold); int8_float16: explicit LayerNorms feeding the quantiser
+struct DecLayerW { LNW ln1, ln2, ln3; LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; LinearW qkv_p, cq_p, ffn1_p; };
 
 enum ProfFamily {
   PF_LOGMEL = 0, PF_ENC_GEMM, PF_ENC_ATTN, PF_ENC_LN, PF_CROSS_KV_GEMM,
@@ -143,7 +144,13 @@ struct Model {
   const half_t* dec_pos = nullptr;  // [n_text_ctx][d]
   std::vector<DecLayerW> dec;
   LinearW logits;  // final LN folded into the tied-embedding projection (fp16) / int8 tied embedding
-  LNW dec_ln;      // int8_float16 only
+  LinearW logits_p;   // fp16: the tied embedding itself, fragment-major (explicit final LayerNorm, ln_unfold >= 1)
+  LNW dec_ln;
+  // fp16 evaluation order of the decoder LayerNorms.  0: folded into the consuming linear (one
+  // launch fewer per LayerNorm; W o g is rounded to fp16 once more and the normalised row is never rounded); 1: the final
+  // LayerNorm is its own kernel — fp16(LN(x)) times the tied embedding, the rounding points of the reference's fp16
+  // path; 2: every decoder LayerNorm is.  FWAMD_LN_UNFOLD at model creation; fw_model_set_ln_unfold.
+  int ln_unfold = 0;
 
   // log-mel constants
   float* lm_consts = nullptr;  // cos table [400] + hann [400]

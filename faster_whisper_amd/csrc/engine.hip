@@ -312,7 +312,11 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   };
   // a decoder linear fed by a LayerNorm: folded in fp16 mode; explicit LN (quantised output) in int8 mode
   auto add_ln_linear = [&](const std::string& base, const std::string& ln, int N, int K) -> int {
-    if (!i8) return add_folded(base, base + ".w", base + ".b", ln + ".g", ln + ".b", N, K);
+    if (!i8) {
+      // both evaluation orders travel in the blob: the folded form and the plain weight + LayerNorm (Model::ln_unfold)
+      int rc = add_folded(base, base + ".w", base + ".b", ln + ".g", ln + ".b", N, K);
+      if (rc) return rc;
+    }
     int rc = add_linear(base, N, K);
     if (rc) return rc;
     if ((rc = add_plain(ln + ".g", {K}))) return rc;
@@ -364,6 +368,10 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
   } else {
     TRY(add_folded("dec.logits", "dec.tok_emb", "", "dec.ln.g", "dec.ln.b", cfg->n_vocab, d));
+    // the explicit order: final LayerNorm as a kernel, then the tied embedding itself (fragment-major copy)
+    TRY(add_plain("dec.tok_emb", {cfg->n_vocab, d}));
+    items.back().name = "dec.logits.wp";
+    TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
   }
 #undef TRY
 
@@ -383,7 +391,8 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     const bool hit = i8 ? (ends("self.qkv.wq") || ends("self.out.wq") || ends("cross.q.wq") || ends("cross.out.wq") ||
                            ends("ffn1.wq") || ends("ffn2.wq") || nm == "dec.logits.wq")
                         : (ends("self.qkv.wf") || ends("self.out.w") || ends("cross.q.wf") || ends("cross.out.w") ||
-                           ends("ffn1.wf") || ends("ffn2.w") || nm == "dec.logits.wf");
+                           ends("ffn1.wf") || ends("ffn2.w") || nm == "dec.logits.wf" || ends("self.qkv.w") ||
+                           ends("cross.q.w") || ends("ffn1.w") || nm == "dec.logits.wp");
     if (!hit) continue;
     const int64_t N = it.dims[0], K = it.dims[1], KE = i8 ? 64 : 32, OCT = KE / 4;
     const bool logits = nm.compare(0, 10, "dec.logits") == 0;
@@ -434,7 +443,8 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   h.n_tensors = (int32_t)items.size();
   h.total_bytes = off;
   h.compute_type = compute_type;
-  h.reserved = 4;   // layout generation: 4 = decoder linears and the vocabulary projection fragment-major
+  h.reserved = 5;   // layout generation: 4 = decoder linears and the vocabulary projection fragment-major; 5 = fp16
+                    // blobs carry the plain (LayerNorm-explicit) forms of qkv / cross.q / ffn1 / logits next to the folded ones
   h.cfg = *cfg;
   memcpy(blob.data(), &h, sizeof(h));
   memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
@@ -592,6 +602,10 @@ static int bind_weights(Model* m) {
       TRY(folded(nm("self.qkv"), &L.qkv, 3 * d, d));
       TRY(folded(nm("cross.q"), &L.cq, d, d));
       TRY(folded(nm("ffn1"), &L.ffn1, 4 * d, d));
+      TRY(ln(nm("ln1"), &L.ln1)); TRY(ln(nm("ln2"), &L.ln2)); TRY(ln(nm("ln3"), &L.ln3));
+      TRY(linear(nm("self.qkv"), &L.qkv_p, 3 * d, d, 0));
+      TRY(linear(nm("cross.q"), &L.cq_p, d, d, 0));
+      TRY(linear(nm("ffn1"), &L.ffn1_p, 4 * d, d, 0));
     }
     TRY(linear(nm("self.out"), &L.out, d, d, 0));
     TRY(linear(nm("cross.kv"), &L.ck, d, d, 0));
@@ -609,6 +623,10 @@ static int bind_weights(Model* m) {
     TRY(ln("dec.ln", &m->dec_ln));
   } else {
     TRY(folded("dec.logits", &m->logits, c.n_vocab, d));
+    m->logits_p = LinearW();
+    TRY(need("dec.logits.wp", &m->logits_p.w));
+    m->logits_p.N = c.n_vocab; m->logits_p.K = d;
+    TRY(ln("dec.ln", &m->dec_ln));
   }
 #undef TRY
   return FW_OK;
@@ -669,9 +687,9 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   Model* m = &fm->impl;
   m->cfg = h.cfg;
   m->compute_type = h.compute_type;
-  if (h.reserved != 4) {
+  if (h.reserved != 5) {
     delete fm;
-    set_error("weight blob was packed by an older libfwamd (layout generation %d, expected 4): repack it", h.reserved);
+    set_error("weight blob was packed by an older libfwamd (layout generation %d, expected 5): repack it", h.reserved);
     return FW_EINVAL;
   }
   m->device = device;
@@ -696,6 +714,10 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   }
   if ((rc = bind_weights(m))) return fail(rc);
   m->is_lane = decoder_lane;
+  {
+    const char* lu = getenv("FWAMD_LN_UNFOLD");   // fp16 evaluation order of the decoder LayerNorms (engine.h)
+    if (lu && lu[0] >= '0' && lu[0] <= '2' && !lu[1]) m->ln_unfold = lu[0] - '0';
+  }
   if (!decoder_lane) {   // (a decode lane has no front end and no encoder: weights, a stream, a decode workspace)
     if ((rc = setup_logmel_consts(m))) return fail(rc);
     if ((rc = alloc_workspaces(m))) return fail(rc);
@@ -1614,6 +1636,33 @@ int32_t fw_test_gemm(fw_model* fm, const float* A, const float* W, const float* 
       rc = run_linear_i8(m, L, dA, nullptr, dC, M, 0, nullptr, 0, 0, M, 1, act_gelu - 2, true, 0);
     else
       rc = run_linear_i8(m, L, dA, nullptr, dC, N, 0, dR, N, 0, M, 1, act_gelu, false, 0);
+  } else if (act_gelu == 8 || act_gelu == 9) {
+    // the cross-attention K (8) / V^T (9) projection epilogues: output MFMA-fragment-major per 64-column head
+    // (gemm.hip), un-permuted here into out [M][N]; the padded keys of the last 32-key group must stay zero
+    const bool vt = act_gelu == 9;
+    if (N % 64 || residual) { set_error("fragment-major gemm test: N %% 64 == 0, no residual"); return FW_EINVAL; }
+    const int kvp = (M + 31) / 32 * 32, H = N / 64;
+    half_t* dF = nullptr;
+    if ((rc = dev_alloc_t(&dF, (size_t)H * kvp * 64))) return rc;
+    FW_HIP(hipMemset(dF, 0, (size_t)H * kvp * 64 * sizeof(half_t)));
+    rc = vt ? run_linear(m, L, dA, K, 0, dF, kvp, 0, nullptr, 0, 0, M, 1, 0, true, kvp)
+            : run_linear(m, L, dA, K, 0, dF, N, 0, nullptr, 0, 0, M, 1, 0, false, kvp);
+    std::vector<float> hf((size_t)H * kvp * 64);
+    if (!rc) rc = download_f16(m, dF, hf.size(), hf.data());
+    (void)hipFree(dF);
+    if (!rc) {
+      for (int mm = 0; mm < kvp && !rc; ++mm)
+        for (int n = 0; n < N; ++n) {
+          const int c = n & 63, r = mm & 31;
+          const size_t off = vt ? (size_t)(n >> 6) * kvp * 64 + ((size_t)((mm >> 5) * 4 + (c >> 4)) * 64 + ((mm >> 3) & 3) * 16 + (c & 15)) * 8 + (mm & 7)
+                                : (size_t)(n >> 6) * kvp * 64 + ((size_t)((mm >> 5) * 4 + 2 * ((r >> 2) & 1) + (c >> 5)) * 64 + ((c >> 3) & 3) * 16 + (((r >> 3) << 2) | (r & 3))) * 8 + (c & 7);
+          if (mm < M) out[(size_t)mm * N + n] = hf[off];
+          else if (hf[off] != 0.f) { set_error("fragment-major epilogue wrote the padded key %d", mm); rc = FW_ERUNTIME; break; }
+        }
+    }
+    for (half_t* p : {dA, dW, dB, dR, dC})
+      if (p) (void)hipFree(p);
+    return rc;
   } else if (act_gelu >= 2) {
     // transposed-output mode: out is [N][M]
     rc = run_linear(m, L, dA, K, 0, dC, M, 0, nullptr, 0, 0, M, 1, act_gelu - 2, true);
@@ -1769,6 +1818,13 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
 }
 
 int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
+
+// process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
+int32_t fw_test_knob(int32_t id, int32_t value) {
+  FW_CHECK_ARG(id == 1, "unknown knob %d", id);
+  fwk::g_gemm_order.store(value);
+  return FW_OK;
+}
 
 int32_t fw_test_dec_logits(fw_model* fm, const float* x, int32_t R, float* out) {
   FW_CHECK_ARG(fm && x && out && R >= 1, "bad argument");
@@ -1990,13 +2046,12 @@ int32_t fw_bench_attention(fw_model* fm, int32_t B, int32_t H, int32_t T, int32_
     FW_HIP(hipMemcpy(dqk, h.data(), nqk * 2, hipMemcpyHostToDevice));
     FW_HIP(hipMemcpy(dvt, h.data(), nvt * 2, hipMemcpyHostToDevice));
   }
-  (void)variant;
   hipEvent_t e0, e1;
   FW_HIP(hipEventCreate(&e0));
   FW_HIP(hipEventCreate(&e1));
-  auto go = [&]() {
+  auto go = [&]() {   // variant: the workgroup -> (chunk, head, query tile) mapping (attn_enc.hip: 0 = XCD-aware, 1 = round 3's)
     fwk::launch_attn_enc(m->stream, dqk, dqk + d, 2 * d, (int64_t)T * 2 * d, dvt, tp, (int64_t)d * tp, dout, d, (int64_t)T * d, B,
-                         H, T);
+                         H, T, variant);
   };
   go();
   FW_HIP(hipEventRecord(e0, m->stream));

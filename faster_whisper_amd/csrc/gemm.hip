@@ -39,10 +39,15 @@
 //    separate transpose pass.
 //  * conv1d (k=3, stride s) over a channel-last, zero-padded image is this GEMM with lda = s*C and K = 3*C: the
 //    three taps of an output row are contiguous in memory.
-//  * 1-D grid with a bijective XCD remap; n fastest inside an m panel so the blocks resident on one XCD share
-//    the A panel and the whole W in that XCD's L2.
+//  * 1-D grid with a bijective XCD remap (an XCD gets a contiguous range of logical tile ids), and the logical ids walk
+//    the (m panel, n tile) plane in BLOCKS of bm x bn tiles (~32 = the workgroups an XCD runs at a time; the m panels
+//    of all chunks of the batch count as one axis: they share W).  What an XCD's L2 has to supply to the 32 workgroups
+//    it runs in near lockstep is then bm A panels + bn W tiles per K tile (4 + 8 = 12 for the 20-tile-wide FFN-up GEMM)
+//    instead of 2 + 20 with n fastest across the whole width — and every byte the L2 misses is HBM bandwidth taken
+//    from the decode runs' cross-attention stream, which is what the chip is short of.
 #include "common.h"
 #include "kernels.h"
+#include <atomic>
 #include <type_traits>
 
 #define GB_M 256
@@ -82,11 +87,24 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 2, wn = wave & 3;
 
-  const int per_z = p.nMt * p.nNt;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int z = bid / per_z;
-  bid -= z * per_z;
-  const int mt = bid / p.nNt, nt = bid - mt * p.nNt;
+  int mp, nt;                                // m panel over all chunks of the batch, n tile
+  if (p.blk_n > 0) {
+    // bands of blk_m panels, inside a band column blocks of blk_n tiles, inside a block n fastest (blk_n divides nNt)
+    const int per_band = p.blk_m * p.nNt;
+    const int band = bid / per_band, r = bid - band * per_band;
+    int bm = p.n_mp - band * p.blk_m; if (bm > p.blk_m) bm = p.blk_m;     // the last band may be short
+    const int per_blk = bm * p.blk_n;
+    const int cb = r / per_blk, rr = r - cb * per_blk;
+    const int mi = rr / p.blk_n;
+    mp = band * p.blk_m + mi;
+    nt = cb * p.blk_n + (rr - mi * p.blk_n);
+  } else {
+    mp = bid / p.nNt;
+    nt = bid - mp * p.nNt;
+  }
+  const int z = mp / p.nMt;
+  const int mt = mp - z * p.nMt;
   const int m0 = mt * GB_M, n0 = nt * GB_N;
 
   const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)z * p.a_bstride * ES;
@@ -316,35 +334,99 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
         }
       }
     }
-  } else if (!TRANS) {
-    // cross-attention K, MFMA-fragment-major per (chunk, head): a 32-key group is 4 runs of 64 lanes x 16 B,
-    // run q = 2*sub + s, lane = 16*g + j  <->  key 32*gi + 8*(j>>2) + 4*sub + (j&3), dims 32*s + 8*g + [0,8)
+  } else if (p.head_rows > 0) {
+    // Cross-attention K (plain) / V^T (TRANS), MFMA-fragment-major per (chunk, head) — the layout dec_cross_attn_kernel
+    // streams: a 32-key group of a head is 4 runs of 64 lanes x 16 B,
+    //   K:    run q = 2*sub + s, lane = 16*g + j  <->  key 32*gi + 8*(j>>2) + 4*sub + (j&3), dims 32*s + 8*g + [0,8)
+    //   V^T:  run dt,            lane = 16*g + j  <->  dim 16*dt + j,                      keys 32*gi + 8*g + [0,8)
+    // A wave's 128 x 64 sub-tile is 128 keys of ONE head = 16 consecutive runs = 16 KB contiguous in the destination,
+    // but the accumulator hands a lane 4 values of one row: stored directly that is 32 eight-byte stores per lane into
+    // 32 different lines per instruction (store-issue bound: these projections ran at 530 TFLOP/s against 950 for the
+    // row-major epilogue).  So the sub-tile goes through the wave's patch of the idle ring, in two halves of 64 keys,
+    // as fp16 [key][dim] (K) or [dim][key] (V^T), and leaves as whole 1 KB runs, 16 B per lane.
+    constexpr int FS = 144;                                  // bytes per staged row: 64 halves + 16
+    char* ep = smem_raw + wave * (64 * FS);
     half_t* Cb = p.C + (size_t)z * p.c_bstride;
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;         // this wave's keys / its head's 64 dims
+    if (nw < p.N) {
+      half_t* Hb = Cb + (size_t)(nw >> 6) * p.head_rows * 64;
+      const int g4 = lane >> 4, j = lane & 15;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 128 + mi * 32 + l31;
-        if (m >= p.M) continue;
-        const float sam = I8 ? sa[m] : 1.f;
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
-          if (n >= p.N) continue;
-          half4_t o;
+          for (int mh = 0; mh < 2; ++mh) {
+            const int mi = half * 2 + mh;
+            if (!TRANS) {
+              const int r = mh * 32 + l31;                   // key inside the half
+              int mc = mw + half * 64 + r; if (mc > p.M - 1) mc = p.M - 1;
+              const float sam = I8 ? sa[mc] : 1.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
-            if (p.bias) v += (float)p.bias[n + e];
-            if (p.act == 1) v = gelu_erf(v);
-            o[e] = (half_t)v;
+              for (int g = 0; g < 4; ++g) {
+                const int c = ni * 32 + 8 * g + 4 * hi;
+                int n = nw + c; if (n > p.N - 4) n = p.N - 4;
+                half4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float v = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
+                  if (p.bias) v += (float)p.bias[n + e];
+                  if (p.act == 1) v = gelu_erf(v);
+                  o[e] = (half_t)v;
+                }
+                *reinterpret_cast<half4_t*>(ep + r * FS + c * 2) = o;
+              }
+            } else {
+              const int c = ni * 32 + l31;                   // dim inside the head
+              int n = nw + c; if (n > p.N - 1) n = p.N - 1;
+              const float bv = p.bias ? (float)p.bias[n] : 0.f;
+              const float swn = I8 ? p.w_scale[n] : 1.f;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int r = mh * 32 + 8 * g + 4 * hi;      // 4 consecutive keys inside the half
+                half4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  int mm = mw + half * 64 + r + e; if (mm > p.M - 1) mm = p.M - 1;
+                  float v = (I8 ? (float)acci[mi][ni][g * 4 + e] * swn * sa[mm] : accf[mi][ni][g * 4 + e]) + bv;
+                  if (p.act == 1) v = gelu_erf(v);
+                  o[e] = (half_t)v;
+                }
+                *reinterpret_cast<half4_t*>(ep + c * FS + r * 2) = o;
+              }
+            }
           }
-          const int c = n & 63, r = m & 31;
-          const int run = (m >> 5) * 4 + 2 * ((r >> 2) & 1) + (c >> 5);
-          const int ln = ((c >> 3) & 3) * 16 + (((r >> 3) << 2) | (r & 3));
-          *reinterpret_cast<half4_t*>(Cb + (size_t)(n >> 6) * p.head_rows * 64 + ((size_t)run * 64 + ln) * 8 + (c & 7)) = o;
+        // (a wave's LDS operations execute in order: the reads below see the writes above)
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+          const int key0 = mw + half * 64 + gl * 32;          // first key of the group
+          if (key0 >= p.M) continue;                          // (wave-uniform)
+          half_t* Gb = Hb + (size_t)(key0 >> 5) * 4 * 512;    // 4 runs of 512 halves
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            intx4 v;
+            if (!TRANS) {
+              const int kl = gl * 32 + 8 * (j >> 2) + 4 * (q >> 1) + (j & 3);
+              v = *reinterpret_cast<const intx4*>(ep + kl * FS + (32 * (q & 1) + 8 * g4) * 2);
+              if (mw + half * 64 + kl < p.M) *reinterpret_cast<intx4*>(Gb + ((size_t)q * 64 + lane) * 8) = v;
+            } else {
+              const int kl = gl * 32 + 8 * g4;                // this lane's 8 consecutive keys
+              v = *reinterpret_cast<const intx4*>(ep + (16 * q + j) * FS + kl * 2);
+              const int left = p.M - (mw + half * 64 + kl);   // keys of the 8 that exist
+              if (left <= 0) continue;
+              if (left < 8) {                                 // the padded keys of the last group stay zero
+                half8_t h = __builtin_bit_cast(half8_t, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (e >= left) h[e] = (half_t)0.f;
+                v = __builtin_bit_cast(intx4, h);
+              }
+              *reinterpret_cast<intx4*>(Gb + ((size_t)q * 64 + lane) * 8) = v;
+            }
+          }
         }
       }
+    }
   } else {
     half_t* Cb = p.C + (size_t)z * p.c_bstride;  // Ct[z][n][m], ldc = row stride of Ct
 #pragma unroll
@@ -366,16 +448,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
             if (p.act == 1) v = gelu_erf(v);
             o[e] = (half_t)v;
           }
-          half_t* dst;
-          if (p.head_rows > 0) {
-            // cross-attention V^T, fragment-major per (chunk, head): run = 4*gi + dt, lane = 16*g + j  <->
-            // dim 16*dt + j, keys 32*gi + 8*g + [0,8)
-            const int c = n & 63;
-            dst = Cb + (size_t)(n >> 6) * p.head_rows * 64 +
-                  ((size_t)((m >> 5) * 4 + (c >> 4)) * 64 + ((m >> 3) & 3) * 16 + (c & 15)) * 8 + (m & 7);
-          } else {
-            dst = Cb + (size_t)n * p.ldc + m;
-          }
+          half_t* dst = Cb + (size_t)n * p.ldc + m;
           if (m + 3 < p.M) {
             *reinterpret_cast<half4_t*>(dst) = o;
           } else {
@@ -390,6 +463,10 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
 
 namespace fwk {
 
+// tile order of launch_gemm: 1 = blocked (the product), 0 = n fastest across the whole width (rounds 1-3); a process-wide
+// knob for the A/B of profiles/gemm_bench.py (fw_test_knob)
+std::atomic<int> g_gemm_order{1};
+
 int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   GemmParams p = pin;
   const bool i8 = p.a_scale != nullptr;
@@ -400,9 +477,20 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   if (i8 && !p.w_scale) return -1;
   p.nMt = (p.M + GB_M - 1) / GB_M;
   p.nNt = (p.N + GB_N - 1) / GB_N;
+  p.n_mp = p.nMt * batch;
+  p.blk_m = p.blk_n = 0;
+  if (g_gemm_order.load(std::memory_order_relaxed) == 1 && p.nNt > 1 && p.n_mp > 1) {
+    int bn = 1;
+    for (int c = 2; c <= 10 && c <= p.nNt; ++c)
+      if (p.nNt % c == 0) bn = c;            // the widest block of at most 10 tiles that divides the width
+    p.blk_n = bn;
+    p.blk_m = 32 / bn > 1 ? 32 / bn : 1;
+  }
   const int lds = GB_LDS_BYTES;  // 128 KiB: one workgroup per CU
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_done{0};   // one bit per device (the limit is a per-device attribute)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, false>),
@@ -411,7 +499,7 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int grid = p.nMt * p.nNt * batch;
   if (i8) {

@@ -1,5 +1,6 @@
 // Host-side launch API of the gfx950 kernels (internal to libfwamd.so).
 #pragma once
+#include <atomic>
 #include "common.h"
 
 namespace fwk {
@@ -27,12 +28,16 @@ struct GemmParams {
   // int8 path (a_scale != null): A and W point to int8 data; dequant scales per A row / per W row
   const float* a_scale; int64_t as_bstride; const float* w_scale;
   int nMt, nNt;                                       // filled by launch_gemm
+  int n_mp, blk_m, blk_n;                             // ... m panels of the whole batch, tile-order block (gemm.hip)
 };
 int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
+extern std::atomic<int> g_gemm_order;                 // tile order knob (gemm.hip), for A/B measurements only
 
 // ---- row kernels (rowops.hip) -----------------------------------------------------
 // y[r] = LN(x[r]) * g + b, eps 1e-5, fp32 statistics (two-pass in registers)
-void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d);
+// frag != 0: y in the MFMA-fragment-major layout of the decoder linears' activations (needs d % 32 == 0)
+void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d,
+                      int frag = 0);
 // per-row dynamic int8 quantisation (absmax / 127), optionally preceded by LayerNorm (g != null):
 // xq[r][:] = rint(y * 127 / absmax(y)), scale[r] = absmax / 127 with y = LN(x[r]) rounded to fp16, or x[r]
 // frag != 0: xq is written MFMA-fragment-major for the int8 register-streaming skinny GEMM (needs d % 64 == 0)
@@ -46,6 +51,6 @@ void launch_f16_to_f32(hipStream_t st, const half_t* x, float* y, int64_t n);
 // out: [B][T][ldo]. softmax(q k^T / 8) v, non-causal, T keys.
 void launch_attn_enc(hipStream_t st, const half_t* q, const half_t* k, int64_t ld, int64_t qk_bstride,
                      const half_t* vt, int64_t ldvt, int64_t vt_bstride, half_t* out, int64_t ldo,
-                     int64_t o_bstride, int B, int H, int T);
+                     int64_t o_bstride, int B, int H, int T, int order = 0);
 
 }  // namespace fwk

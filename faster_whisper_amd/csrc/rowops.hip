@@ -57,9 +57,11 @@ static __device__ __forceinline__ float normalise_row(float (&v)[MAXC][8], int n
   return amax;
 }
 
+// frag != 0: y is MFMA-fragment-major (the layout the decoder linears read, dec_kernels.hip frag_off): the 8 halves
+// k = 8c .. 8c+7 of row r stay one 16-byte chunk at ((r/16 * d/32 + c/4) * 64 + 16*(c%4) + r%16) * 8
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ g,
                                                         const half_t* __restrict__ b, half_t* __restrict__ y,
-                                                        int rows, int d) {
+                                                        int rows, int d, int frag) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -75,7 +77,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
       half8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (half_t)v[i][e];
-      *reinterpret_cast<half8_t*>(yr + (size_t)c * 8) = o;
+      if (frag)
+        *reinterpret_cast<half8_t*>(y + ((size_t)((row >> 4) * (d >> 5) + (c >> 2)) * 64 + (c & 3) * 16 + (row & 15)) * 8) = o;
+      else
+        *reinterpret_cast<half8_t*>(yr + (size_t)c * 8) = o;
     }
   }
 }
@@ -143,8 +148,9 @@ __global__ void f16_to_f32_kernel(const half_t* __restrict__ x, float* __restric
 }
 
 namespace fwk {
-void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d) {
-  layernorm_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, g, b, y, rows, d);
+void launch_layernorm(hipStream_t st, const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int d,
+                      int frag) {
+  layernorm_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, g, b, y, rows, d, frag);
 }
 static int grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;

@@ -50,12 +50,16 @@ int32_t fw_test_layernorm(fw_model* m, const float* x, const float* g, const flo
 int32_t fw_test_attention(fw_model* m, const float* q, const float* k, const float* v,
                           int32_t B, int32_t H, int32_t T, float* out);
 /* measurement hook (profiles/attn_bench.py): mean milliseconds of one launch of the encoder self-attention kernel for
- * B chunks x H heads x T positions on device-resident pseudo-random operands; variant is reserved (pass 0) */
+ * B chunks x H heads x T positions on device-resident pseudo-random operands; variant = the workgroup mapping
+ * (0: XCD-aware, the product's; 1: query tile fastest over all XCDs, round 3's) */
 int32_t fw_bench_attention(fw_model* m, int32_t B, int32_t H, int32_t T, int32_t variant, int32_t iters, float* ms_out);
 
 /* rows from which a decode run's per-layer linears take the GEMM-shaped kernel (dec_kernels.hip: DEC_BIG_MIN_ROWS);
  * bench.py prices the decoder linears against the MFMA roof from this row count on, against HBM below */
 int32_t fw_dec_big_min_rows(void);
+/* process-wide measurement knob for A/B runs inside one process.  id 1: encoder GEMM tile order (1 = blocked, the
+ * product's; 0 = n fastest across the whole width, rounds 1-3) */
+int32_t fw_test_knob(int32_t id, int32_t value);
 
 #ifdef __cplusplus
 }

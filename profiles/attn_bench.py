@@ -16,9 +16,10 @@ def main():
     ms = C.c_float()
     B, H, T = 16, 20, 1500
     fl = 4.0 * B * H * T * T * 64
-    for rnd in range(3):
-        _lib.check(m._lib.fw_bench_attention(h, B, H, T, 0, 50, C.byref(ms)))
-        print(f"round {rnd}: {ms.value * 1e3:.1f} us per launch, {fl / ms.value / 1e9:.0f} TFLOP/s", flush=True)
+    for rnd in range(3):          # interleaved A/B in one process (variant: attn_enc.hip workgroup mapping)
+        for variant, what in ((0, "XCD-aware grid"), (1, "round-3 grid")):
+            _lib.check(m._lib.fw_bench_attention(h, B, H, T, variant, 50, C.byref(ms)))
+            print(f"round {rnd} {what}: {ms.value * 1e3:.1f} us per launch, {fl / ms.value / 1e9:.0f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,11 @@ def main():
     ap.add_argument("--pad", default="0")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--square", default="",
+                    help="comma-separated sizes n: time the kernel at n x n x n (batch 1) — the guide quotes its 256^2 "
+                         "8-phase template at 4096^3 / 8192^3 on random operands (cdna_hip_programming.md), where a launch "
+                         "is exactly one or four full rounds of 256 workgroups and K is 64-128 tiles deep; the encoder "
+                         "shapes are 1.9-7.5 rounds and 6-80 K tiles")
     args = ap.parse_args()
     from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights
     cfg = get_config("micro")
@@ -32,17 +37,34 @@ def main():
     lib = _lib.load()
     h = model._replicas[0].handle
     out = {"env": {k: v for k, v in os.environ.items() if k.startswith("FWAMD_")}, "int8": args.int8}
-    for pad in [int(x) for x in args.pad.split(",")]:
-        tot_ms = tot_fl = 0.0
-        weights = {"conv1": 1, "conv2": 1, "qk": 32, "v^T": 32, "out": 32, "ffn1": 32, "ffn2": 32}
-        for name, M, N, K, tr in SHAPES:
+    if args.square:
+        for n in [int(x) for x in args.square.split(",")]:
             ms = C.c_float()
-            _lib.check(lib.fw_bench_gemm(h, M, N, K, args.batch, pad, pad, tr, args.iters, C.byref(ms)))
-            fl = 2.0 * args.batch * M * N * K
-            out[f"{name} pad={pad}"] = {"ms": round(ms.value, 4), "TFLOP/s": round(fl / ms.value / 1e9, 1)}
-            tot_ms += ms.value * weights[name]
-            tot_fl += fl * weights[name]
-        out[f"encoder-weighted pad={pad}"] = {"ms": round(tot_ms, 2), "TFLOP/s": round(tot_fl / tot_ms / 1e9, 1)}
+            _lib.check(lib.fw_bench_gemm(h, n, n, n, 1, 0, 0, 0, args.iters, C.byref(ms)))
+            out[f"square {n}"] = {"ms": round(ms.value, 4), "TFLOP/s": round(2.0 * n * n * n / ms.value / 1e9, 1)}
+        print(json.dumps(out, indent=1))
+        return
+    weights = {"conv1": 1, "conv2": 1, "qk": 32, "v^T": 32, "out": 32, "ffn1": 32, "ffn2": 32}
+    for pad in [int(x) for x in args.pad.split(",")]:
+        # tile order A/B, interleaved shape by shape in one process (fw_test_knob 1: 1 = blocked, 0 = n fastest)
+        tot = {1: [0.0, 0.0], 0: [0.0, 0.0]}
+        for name, M, N, K, tr in SHAPES:
+            for order in (1, 0, 1, 0):
+                _lib.check(lib.fw_test_knob(1, order))
+                ms = C.c_float()
+                _lib.check(lib.fw_bench_gemm(h, M, N, K, args.batch, pad, pad, tr, args.iters, C.byref(ms)))
+                fl = 2.0 * args.batch * M * N * K
+                key = f"{name} pad={pad} order={order}"
+                prev = out.get(key)
+                if prev is None or ms.value < prev["ms"]:
+                    out[key] = {"ms": round(ms.value, 4), "TFLOP/s": round(fl / ms.value / 1e9, 1)}
+            for order in (1, 0):
+                tot[order][0] += out[f"{name} pad={pad} order={order}"]["ms"] * weights[name]
+                tot[order][1] += 2.0 * args.batch * M * N * K * weights[name]
+        for order in (1, 0):
+            out[f"encoder-weighted pad={pad} order={order}"] = {"ms": round(tot[order][0], 2),
+                                                               "TFLOP/s": round(tot[order][1] / tot[order][0] / 1e9, 1)}
+    _lib.check(lib.fw_test_knob(1, 1))
     print(json.dumps(out, indent=1))
 
 

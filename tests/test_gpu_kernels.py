@@ -201,6 +201,29 @@ def test_dec_linear_layernorm_folded_gelu(model, R, N, K):
         assert np.array_equal(out, out_frag)
 
 
+@pytest.mark.parametrize("M,N,K", [(1500, 1280, 256), (77, 128, 128), (1031, 256, 128), (1500, 384, 384), (32, 64, 64),
+                                   (1473, 128, 192)])
+@pytest.mark.parametrize("vt", [False, True])
+def test_gemm_cross_kv_fragment_major(model, M, N, K, vt):
+    """the cross-attention K / V^T projection epilogues (gemm.hip: the sub-tile staged through LDS, whole 1 KB runs of
+    the MFMA-fragment-major layout dec_cross_attn_kernel streams): the hook un-permutes the device buffer on the host
+    and fails if a padded key (>= M inside the last 32-key group, M = 1500 / 77 / 1031 / 1473: 4, 19, 25 and 31 of them)
+    was written.  Asymmetric operands: a transposed or mis-grouped run cannot pass."""
+    rng = np.random.default_rng(M + 3 * N + K + int(vt))
+    A = _h((rng.standard_normal((M, K)) * (1.0 + np.arange(M)[:, None] / M)).astype(np.float32))
+    W = _h((rng.standard_normal((N, K)) * (0.5 + np.arange(N)[:, None] / N)).astype(np.float32))
+    b = _h(0.3 * rng.standard_normal(N).astype(np.float32))
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    out = np.zeros((M, N), np.float32)
+    _lib.check(lib.fw_test_gemm(model._replicas[0].handle, _lib.ptr(np.ascontiguousarray(A)), _lib.ptr(np.ascontiguousarray(W)),
+                                _lib.ptr(b), None, M, N, K, 9 if vt else 8, 0, _lib.ptr(out)))
+    ref = A @ W.T + b
+    err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+    print(f"cross-{'V^T' if vt else 'K'} projection {M}x{N}x{K}: rel err {err:.2e}")
+    assert err < 2e-3
+
+
 BIG_CFGS = (0, 1, 2)     # workgroup shapes of dec_gemm_big_kernel (dec_kernels.hip: launch_dec_gemm_big)
 
 
