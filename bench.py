@@ -416,8 +416,10 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             if hasattr(model, "set_decode_lanes"):
                 model.set_decode_lanes(1)
             model.profile(True, replica=None)
+            ps0 = model.decode_stats()
             run_steps(W, gather=False)
             model.synchronize()
+            ps1 = model.decode_stats()
             rep = model.profile_report(replica=None)
             model.profile(False, replica=None)
             if hasattr(model, "set_decode_lanes"):
@@ -429,7 +431,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             # Dominant KERNEL = the kernel symbol with the largest share of the step.  The decoder linears are three
             # instantiations of dec_gemm_frag_kernel (LayerNorm-folded / plain / long-K), timed here as four role
             # families (qkv, d x d, ffn1, ffn2): together they are listed under roofline_others as "dec_gemm".
-            rows_per_run = args.beam * (stats1["chunks"] - stats0["chunks"]) / runs
+            # (the decode runs of the PROFILED round: one lane, W batches — not those of the timed region)
+            rows_per_run = args.beam * (ps1["chunks"] - ps0["chunks"]) / max(1, ps1["runs"] - ps0["runs"])
             # runs of at least DEC_BIG_MIN_ROWS rows take the GEMM-shaped kernel (dec_gemm_big_kernel) and are priced against
             # the MFMA roof; below it the linears are weight-streaming launches priced against HBM
             big_rows = model.dec_big_min_rows() if hasattr(model, "dec_big_min_rows") else 1024

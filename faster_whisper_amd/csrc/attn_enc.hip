@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[0][r]), s[1][r]);   // -> v_max3_f32
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = pair32_max(mx);                     // the partner lane holds the query's other 32 keys of the tile
     const float m_new = fmaxf(m_run, mx);
     // rescale only when some query of the wave saw a larger score (wave-uniform: no divergence)
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
   }
 
   // ---- normalise and store: lane = query, 4 consecutive dh per register group ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = pair32_sum(l_run);
   const float inv = 1.0f / l_tot;
   const int qr = q0 + wave * 32 + l31;
   if (qr < T) {

@@ -27,6 +27,27 @@ static __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Exchange with the lane 32 (16) away on the VALU: gfx950's v_permlane32_swap / v_permlane16_swap instead of the
+// ds_bpermute round trip through the LDS crossbar that __shfl_xor compiles to.  With both operands the same value v,
+// the two results hold {own, partner's} in some order in every lane; max and + do not care which is which, and the
+// two lanes of a pair compute the same operation on the same two numbers: the same bits in both, as before.
+static __device__ __forceinline__ float pair32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+static __device__ __forceinline__ float pair32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+static __device__ __forceinline__ float pair16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+static __device__ __forceinline__ float pair16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
 // exact (erf) GELU, as in openai-whisper / CTranslate2
 static __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

@@ -728,6 +728,17 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
 // load instruction = 8 whole rows, 8 position groups per wave, 4 loads in flight per lane), reduced by shuffles.
 // ------------------------------------------------------------------------------------
 #define SA_MAX_CTX 448
+// sum over the 8 lanes that share a position (lanes 8g .. 8g+7), result in all of them: two quad permutes and a
+// half-row mirror on the DPP path of the VALU instead of three ds_bpermute round trips through the LDS crossbar (what
+// __shfl_xor compiles to: the dependent chain of a score was 3 x (bpermute + lgkmcnt wait + add), ~250 cycles; the
+// kernel is issue / latency bound, not bandwidth bound).  Same additions as the xor-1 / xor-2 / xor-4 butterfly — fp
+// addition commutes — so every lane gets the bits it got before.
+static __device__ __forceinline__ float sum8_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
 __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
                                                              half_t* __restrict__ vc, int n_ctx, int cache_ctx,
                                                              int H, const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
@@ -764,10 +775,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const half_t* __res
     float sacc = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sacc += q[e] * (float)k[e];
-    sacc += __shfl_xor(sacc, 1, 64);
-    sacc += __shfl_xor(sacc, 2, 64);
-    sacc += __shfl_xor(sacc, 4, 64);
-    return sacc;                               // the 8 lanes of a position all hold its score
+    return sum8_dpp(sacc);                     // the 8 lanes of a position all hold its score
   };
   const float s_new = dot8(kn8);
   float mx = s_new;
@@ -926,8 +934,8 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
       sc[e] = v;
       mx = fmaxf(mx, v);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = pair16_max(mx);
+    mx = pair32_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
@@ -952,8 +960,8 @@ __global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const hal
     }
   }
   // combine the 4 key-group lanes of a query, then the 4 waves
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run = pair16_sum(l_run);
+  l_run = pair32_sum(l_run);
   if (g == 0) { sm[wave][j] = m_run; sl[wave][j] = l_run; }
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)

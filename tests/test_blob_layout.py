@@ -17,7 +17,7 @@ def test_fragment_major_decoder_linears():
     cfg = get_config("micro")
     w = synthetic_weights(cfg, seed=4)
     h, t = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_FLOAT16))
-    assert h.reserved == 4
+    assert h.reserved == 5
     for name in ("dec.0.self.out.w", "dec.1.cross.out.w", "dec.0.ffn2.w"):
         assert np.array_equal(t[name], frag_perm(_h(w[name]))), name
     # LayerNorm-folded ones: (W * g) rounded to fp16, then permuted; s1 / cf stay plain
@@ -35,6 +35,14 @@ def test_fragment_major_decoder_linears():
     un = frag_unperm(t["dec.logits.wf"])
     assert np.array_equal(un[:V], lg) and not un[V:].any()
     assert t["dec.logits.s1"].shape == (V,)
+    # layout generation 5: the explicit-LayerNorm forms travel too — plain weights fragment-major, LayerNorm gain / bias,
+    # the tied embedding as a fragment-major projection (zero-padded like the folded one)
+    for name in ("dec.0.self.qkv.w", "dec.1.cross.q.w", "dec.1.ffn1.w"):
+        assert np.array_equal(t[name], frag_perm(_h(w[name]))), name
+    assert np.array_equal(t["dec.1.ln3.g"], _h(w["dec.1.ln3.g"])) and np.array_equal(t["dec.ln.b"], _h(w["dec.ln.b"]))
+    up = frag_unperm(t["dec.logits.wp"])
+    assert np.array_equal(up[:V], _h(w["dec.tok_emb"])) and not up[V:].any()
+    assert np.array_equal(t["dec.tok_emb"], _h(w["dec.tok_emb"]))      # the embedding lookup keeps its row-major copy
     # the permutation is a bijection of the tile grid: every lane's 16 bytes are 8 consecutive k of one row
     x = np.arange(32 * 64, dtype=np.float32).reshape(32, 64)
     f = frag_perm(x).reshape(-1, 8)
@@ -49,7 +57,7 @@ def test_int8_fragment_major_decoder_linears():
     cfg = get_config("micro")
     w = synthetic_weights(cfg, seed=6)
     h1, t1 = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_INT8_FLOAT16))
-    assert h1.reserved == 4
+    assert h1.reserved == 5
     o = OracleWhisper(cfg, w, int8=True)
     for name in ("dec.0.self.qkv", "dec.1.ffn2", "dec.0.cross.out"):
         wq = o.q[name + ".w"][0].numpy().astype(np.int8)
