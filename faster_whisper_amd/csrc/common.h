@@ -31,22 +31,27 @@ static __device__ __forceinline__ float wave_max(float v) {
 // ds_bpermute round trip through the LDS crossbar that __shfl_xor compiles to.  With both operands the same value v,
 // the two results hold {own, partner's} in some order in every lane; max and + do not care which is which, and the
 // two lanes of a pair compute the same operation on the same two numbers: the same bits in both, as before.
-static __device__ __forceinline__ float pair32_max(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+// (The two results are copied into scalars before the bit cast: __builtin_bit_cast applied to a vector ELEMENT
+//  expression reads the vector's first element whatever the index — hipcc 7.2 emitted max(r0, r0) / r0 + r0 for
+//  bit_cast(r[0]) op bit_cast(r[1]).)
+static __device__ __forceinline__ void pair_swap32(float v, float& a, float& b) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
 }
-static __device__ __forceinline__ float pair32_sum(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+static __device__ __forceinline__ void pair_swap16(float v, float& a, float& b) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
 }
-static __device__ __forceinline__ float pair16_max(float v) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-static __device__ __forceinline__ float pair16_sum(float v) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-}
+static __device__ __forceinline__ float pair32_max(float v) { float a, b; pair_swap32(v, a, b); return fmaxf(a, b); }
+static __device__ __forceinline__ float pair32_sum(float v) { float a, b; pair_swap32(v, a, b); return a + b; }
+static __device__ __forceinline__ float pair16_max(float v) { float a, b; pair_swap16(v, a, b); return fmaxf(a, b); }
+static __device__ __forceinline__ float pair16_sum(float v) { float a, b; pair_swap16(v, a, b); return a + b; }
 
 // exact (erf) GELU, as in openai-whisper / CTranslate2
 static __device__ __forceinline__ float gelu_erf(float x) {

@@ -480,9 +480,16 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   p.n_mp = p.nMt * batch;
   p.blk_m = p.blk_n = 0;
   if (g_gemm_order.load(std::memory_order_relaxed) == 1 && p.nNt > 1 && p.n_mp > 1) {
-    int bn = 1;
-    for (int c = 2; c <= 10 && c <= p.nNt; ++c)
-      if (p.nNt % c == 0) bn = c;            // the widest block of at most 10 tiles that divides the width
+    // L2 fill traffic of a block of bm x bn tiles that an XCD's 32 workgroups run in near lockstep is (bm + bn) operand
+    // panels (measured: the out-projection, 6.4 + 5 panels per 32 tiles, fetches 119 MB = that model's 112; the FFN-up
+    // GEMM with n fastest across its 20 tiles, 1.6 + 20 panels, fetched 0.85-0.9 GB per launch against 74 MB of
+    // operands): the divisor of the width that makes the block squarest, bm = 32 / bn
+    int bn = 1, best = 1 << 30;
+    for (int c = 1; c <= p.nNt && c <= 16; ++c) {
+      if (p.nNt % c) continue;
+      const int cost = c + (32 + c - 1) / c;
+      if (cost <= best) { best = cost; bn = c; }
+    }
     p.blk_n = bn;
     p.blk_m = 32 / bn > 1 ? 32 / bn : 1;
   }

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--pad", default="0")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--order", type=int, default=-1, help="tile order of every launch (1 blocked, 0 n fastest); default: A/B")
     ap.add_argument("--square", default="",
                     help="comma-separated sizes n: time the kernel at n x n x n (batch 1) — the guide quotes its 256^2 "
                          "8-phase template at 4096^3 / 8192^3 on random operands (cdna_hip_programming.md), where a launch "
@@ -49,7 +50,7 @@ def main():
         # tile order A/B, interleaved shape by shape in one process (fw_test_knob 1: 1 = blocked, 0 = n fastest)
         tot = {1: [0.0, 0.0], 0: [0.0, 0.0]}
         for name, M, N, K, tr in SHAPES:
-            for order in (1, 0, 1, 0):
+            for order in ((1, 0, 1, 0) if args.order < 0 else (args.order,)):
                 _lib.check(lib.fw_test_knob(1, order))
                 ms = C.c_float()
                 _lib.check(lib.fw_bench_gemm(h, M, N, K, args.batch, pad, pad, tr, args.iters, C.byref(ms)))
@@ -58,10 +59,10 @@ def main():
                 prev = out.get(key)
                 if prev is None or ms.value < prev["ms"]:
                     out[key] = {"ms": round(ms.value, 4), "TFLOP/s": round(fl / ms.value / 1e9, 1)}
-            for order in (1, 0):
+            for order in ((1, 0) if args.order < 0 else (args.order,)):
                 tot[order][0] += out[f"{name} pad={pad} order={order}"]["ms"] * weights[name]
                 tot[order][1] += 2.0 * args.batch * M * N * K * weights[name]
-        for order in (1, 0):
+        for order in ((1, 0) if args.order < 0 else (args.order,)):
             out[f"encoder-weighted pad={pad} order={order}"] = {"ms": round(tot[order][0], 2),
                                                                "TFLOP/s": round(tot[order][1] / tot[order][0] / 1e9, 1)}
     _lib.check(lib.fw_test_knob(1, 1))
