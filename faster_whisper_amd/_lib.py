@@ -6,7 +6,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfwamd.so")
+# FWAMD_LIB: another build of the library (A/B of two builds on one GPU box: profiles/r04_ab_builds.sh); the product
+# loads the in-tree libfwamd.so
+LIB_PATH = os.environ.get("FWAMD_LIB") or os.path.join(_HERE, "libfwamd.so")
 
 FW_OK = 0
 FW_EINVAL = -1
@@ -111,7 +113,8 @@ def load():
     lib.fw_model_run_capacity.argtypes = [vp]
     lib.fw_model_run_capacity.restype = i32
     lib.fw_dec_big_min_rows.restype = i32
-    lib.fw_test_knob.argtypes = [i32, i32]
+    if hasattr(lib, "fw_test_knob"):          # (absent from the older build an A/B loads through FWAMD_LIB)
+        lib.fw_test_knob.argtypes = [i32, i32]
     lib.fw_model_join_decoder.argtypes = [vp, vp]
     lib.fw_model_set_merge_wait.argtypes = [vp, i32, i32]
     lib.fw_model_set_decode_lanes.argtypes = [vp, i32]
