@@ -564,7 +564,8 @@ def one_batch(model, staged, chunks, prompt, kw, L, batch, reps=4):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-PMC_FETCH_FILE = "r03_pmc_fetch.json"     # the round's counter pass (profiles/collect.sh r03)
+PMC_FETCH_FILE = "r04_pmc_fetch.json"     # the round's counter passes (profiles/collect.sh r04): one batch per decode
+PMC_FETCH_MERGED_FILE = "r04_pmc_fetch_w32.json"   # run, and the timed configuration (32 workers, merged runs)
 _PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "gemm_f16", "enc_attn": "attn_enc_kernel",
                "dec_gemm": "dec_gemm_frag_kernel", "dec_self_attn": "dec_self_attn_kernel",
                "dec_logits": "dec_gemm_wave_kernel"}
@@ -575,10 +576,27 @@ def pmc_traffic(family):
     (profiles/rNN_pmc_fetch*.json, x2 gfx950 correction already applied by profiles/parse_pmc.py); null if that
     kernel was not measured."""
     import glob
+    if family not in _PMC_KERNEL:
+        return None
+    merged = os.path.join(ROOT, "profiles", PMC_FETCH_MERGED_FILE)
+    if family == "dec_cross_attn" and os.path.exists(merged):
+        # the dominant kernel: FETCH_SIZE from the pass that ran the TIMED configuration (merged decode runs); the launch's
+        # grid gives the chunks it streamed, hence its algorithmic bytes (profiles/parse_pmc.py)
+        with open(merged) as f:
+            j = json.load(f)
+        for k, v in j.items():
+            if _PMC_KERNEL[family] in k and v.get("algorithmic_bytes_per_launch"):
+                return {"hbm_read_bytes_per_launch": round(v["hbm_read_bytes_per_launch_corrected"]),
+                        "algorithmic_bytes_per_launch_in_that_pass": round(v["algorithmic_bytes_per_launch"]),
+                        "chunks_per_launch_in_that_pass": round(v["chunks_per_launch_mean"], 1),
+                        "source": os.path.relpath(merged, ROOT),
+                        "note": "mean over the launches of that kernel in the counter pass of the timed configuration "
+                                "(profiles/collect.sh: the bench command with 32 workers, one decode lane, eager decode "
+                                "step: merged decode runs)"}
     files = [os.path.join(ROOT, "profiles", PMC_FETCH_FILE)]
     if not os.path.exists(files[0]):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch*.json")))
-    if not files or family not in _PMC_KERNEL:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch.json")))
+    if not files:
         return None
     path = files[-1]
     with open(path) as f:

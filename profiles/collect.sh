@@ -9,11 +9,13 @@
 #   kernel_stats_w32.csv        the same with the bench's 32 workers: merged decode runs next to the encoders (durations
 #                               of concurrent kernels overlap in this one: read it for the decode stream)
 #   pmc_fetch.json              FETCH_SIZE per kernel (x2 gfx950 correction applied by parse_pmc.py), one batch at a time
+#   pmc_fetch_w32.json          the same for the configuration that is TIMED: 32 workers, merged decode runs (one lane);
+#                               parse_pmc.py derives the chunks of the mean cross-attention launch from its grid
 #   pmc_sq.json                 SQ wait / active / MFMA-busy / LDS-conflict counters per kernel, one batch at a time
 # Counter passes are separate runs with --pmc only (gpurun refuses --pmc combined with the trace domains).
 # The decode step runs eagerly under the profiler (FWAMD_NO_GRAPH=1): rocprofv3 7.2 crashes on replayed hipGraphs.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -44,6 +46,7 @@ pmc() {     # name, bench args ... -- counters...
 trace w1 --workers 1 --steps 2 --warmup 1
 trace w32 --steps 64 --warmup 1
 pmc fetch --workers 1 --steps 2 --warmup 1 -- FETCH_SIZE
+pmc fetch_w32 --steps 32 --warmup 1 -- FETCH_SIZE
 pmc sq --workers 1 --steps 1 --warmup 1 -- SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 cd "$R"
 cp "$OUT/pmc_fetch.json" "$R/profiles/${TAG}_pmc_fetch.json" 2>/dev/null
