@@ -131,6 +131,8 @@ def build_backend(args, cfg, rank, world, local_rank):
                   inter_threads=args.workers, compute_type=args.compute_type)
     if getattr(args, "merge_fill", None) is not None:
         common["merge_fill_percent"] = args.merge_fill
+    if getattr(args, "merge_wait_ms", None) is not None:
+        common["merge_wait_ms"] = args.merge_wait_ms
     weights = None
     if _multi(world):
         blob = None
@@ -219,6 +221,9 @@ def parse_args(argv=None):
                          "traces in profiles/ so that kernel durations are not stretched by the other lane's kernels)")
     ap.add_argument("--merge-fill", type=int, default=None,
                     help="share (percent) of a decode run's chunk capacity the leader of a run waits for (backend default 90)")
+    ap.add_argument("--merge-wait-ms", type=int, default=None,
+                    help="how long the leader of a decode run waits after the last arrival for workers that are still encoding "
+                         "(backend default: one measured encoder pass, at most 120 ms)")
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
                     help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
     ap.add_argument("--word-timestamps", action="store_true",

@@ -34,6 +34,7 @@
 #define AE_Q 128
 #define AE_KV 64
 #define AE_VSTRIDE 68 /* halves per V^T tile row (136 B) */
+#define AE_LAG 5.0f   /* how far (log2 domain) a query's scores may run ahead of its softmax reference: P <= 32 */
 
 __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
                                                        int64_t ld, int64_t qk_bstride,
@@ -103,7 +104,21 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
   __syncthreads();
 
   floatx16 o[2] = {floatx16{0}, floatx16{0}};
-  float m_run = -1.0e30f, l_run = 0.f;
+  // The softmax denominator rides on the matrix pipe: lsum += ONES x P^T with the same fp16 P fragments the PV product
+  // consumes (every row of the tile = sum over the 16 keys of a fragment, per query = per lane: both lane halves already
+  // folded in).  The kernel is bound by its vector instructions (SQ counters) with the MFMA pipe 27 %
+  // busy: 4 MFMAs per tile replace 32 v_add per lane and the final cross-half exchange; and the denominator is the sum
+  // of exactly the P values the numerator used.
+  floatx16 lsum = floatx16{0};
+  const half8_t ones8 = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+  // The softmax reference rides on the matrix pipe too: the scores leave the QK^T MFMAs already relative to a per-query
+  // reference m_ref (the C operand of the first MFMA of a tile is a tile of -m_ref), so a tile whose scores stay within
+  // AE_LAG of the reference needs no subtraction at all (32 v_sub per lane and tile otherwise).  m_ref is the running
+  // maximum as of its last update: it is set from the first tile, and raised (accumulators rescaled, as before) only
+  // when some query of the wave sees a score more than AE_LAG above it — so the largest P of a query stays within
+  // [1, 2^AE_LAG]: no overflow of the fp16 P fragments, no underflow of the terms that matter.
+  float m_ref = 0.f;
+  floatx16 cneg = floatx16{0};               // -m_ref in every register (a lane's 16 rows belong to one query)
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
     if (more) gload(kt + 1);
 
     // ---- S^T[key][query] for the 64 keys of this tile ----
-    floatx16 s[2] = {floatx16{0}, floatx16{0}};
+    floatx16 s[2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int chunk = ks * 2 + hi;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         const int row = kb2 * 32 + l31;
         const half8_t kf = *reinterpret_cast<const half8_t*>(&sK[cur][row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3)]);
-        s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb2], 0, 0, 0);
+        s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? cneg : s[kb2], 0, 0, 0);
       }
     }
     // ---- online softmax (one query per lane; partner lane^32 holds the other keys) ----
@@ -138,27 +153,28 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[0][r]), s[1][r]);   // -> v_max3_f32
     mx = pair32_max(mx);                     // the partner lane holds the query's other 32 keys of the tile
-    const float m_new = fmaxf(m_run, mx);
-    // rescale only when some query of the wave saw a larger score (wave-uniform: no divergence)
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
+    // mx is relative to m_ref.  Move the reference only for the first tile (it fixes the reference: any sign) or when
+    // some query of the wave ran more than AE_LAG ahead of it (wave-uniform branch: no divergence; then every lane
+    // raises its own reference to its own maximum, which is always allowed)
+    if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > AE_LAG) != 0) {
+      const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_ref += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { cneg[r] = -m_ref; lsum[r] *= alpha; }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb2][r] -= delta;
     }
-    float psum = 0.f;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb2][r] - m_run);
-        s[kb2][r] = pv;
-        psum += pv;
-      }
-    l_run += psum;
+      for (int r = 0; r < 16; ++r) s[kb2][r] = __builtin_amdgcn_exp2f(s[kb2][r]);
 
     // ---- O^T[dh][query] += V^T[dh][key] * P^T[key][query] ----
 #pragma unroll
@@ -171,6 +187,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
           const half2_t h2 = {(half_t)s[kb2][ks2 * 8 + e], (half_t)s[kb2][ks2 * 8 + e + 1]};
           pf[e] = h2[0]; pf[e + 1] = h2[1];
         }
+        lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf, lsum, 0, 0, 0);
         const int koff = kb2 * 32 + ks2 * 16 + 4 * hi;  // keys koff+{0..3}, koff+8+{0..3}
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -189,8 +206,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
   }
 
   // ---- normalise and store: lane = query, 4 consecutive dh per register group ----
-  const float l_tot = pair32_sum(l_run);
-  const float inv = 1.0f / l_tot;
+  const float inv = 1.0f / lsum[0];             // (every row of lsum holds the query's whole sum)
   const int qr = q0 + wave * 32 + l31;
   if (qr < T) {
     half_t* op = out + (size_t)b * o_bstride + (size_t)qr * ldo + h * 64;

@@ -252,3 +252,86 @@ def test_decode_batch_cannot_change_under_a_run():
     for a, b in zip(out, ref):
         assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
     assert lib.fw_model_set_decode_batch(h, 12) == 0 and model.decode_stats()["decode_batch"] == 12
+
+
+def test_cross_kv_pool_blocks_are_found_again_and_recycled():
+    """The cross-attention K / V^T of a decode group live in ONE pool of per-encoder-output blocks (decoder.hip:
+    CrossPool), shared by the lanes.  detect_language, generate and align on the same encoder output find its block
+    again; encoder outputs beyond the pool's block count recycle the least recently used block; results never depend on
+    which block (or which lane) served a call."""
+    cfg, model = _model("micro", 4)                       # 4 blocks of 3 chunk slots, two lanes
+    st = model.decode_stats()
+    assert st["decode_batch"] == 12 and st["run_capacity"] == 12
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True, return_no_speech_prob=True)
+    batches = _batches(7, 3)                              # more encoder outputs than blocks
+    encs = [model.encode_pcm(b) for b in batches]
+    first = []
+    for e in encs:                                        # every call takes (and recycles) a block
+        first.append((model.detect_language(e), model.generate(e, [prompt] * 3, **kw),
+                      model.align(e, cfg.sot_sequence, [[11, 12, 13]] * 3, [3000] * 3)))
+    for e, (dl, gen, al) in zip(reversed(encs), reversed(first)):   # again, in another order: blocks long recycled
+        dl2, gen2 = model.detect_language(e), model.generate(e, [prompt] * 3, **kw)
+        al2 = model.align(e, cfg.sot_sequence, [[11, 12, 13]] * 3, [3000] * 3)
+        assert dl2 == dl
+        for a, b in zip(gen2, gen):
+            assert a.sequences_ids == b.sequences_ids and a.scores == b.scores and a.no_speech_prob == b.no_speech_prob
+        for a, b in zip(al2, al):
+            assert a.alignments == b.alignments and a.text_token_probs == b.text_token_probs
+
+
+def test_a_call_that_cannot_fit_a_run_is_refused_at_entry():
+    """random sampling runs every hypothesis as a row of its own: batch x num_hypotheses x positions beyond what ONE decode
+    run holds is a ValueError for that caller alone, raised before the call is queued (it must not take down the calls
+    it would have been merged with), and the model keeps working"""
+    cfg, model = _model("micro", 2)                       # 6 chunks x beam 5 = 30 rows per run
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    e = model.encode_pcm(_batches(1, 3)[0])
+    with pytest.raises(ValueError, match="decoder rows"):
+        model.generate(e, [prompt] * 3, beam_size=1, num_hypotheses=11, sampling_topk=0, sampling_temperature=0.9,
+                       max_length=len(prompt) + 8)
+    ok = model.generate(e, [prompt] * 3, beam_size=1, num_hypotheses=10, sampling_topk=0, sampling_temperature=0.9,
+                        max_length=len(prompt) + 8, seed=3, return_scores=True)
+    assert len(ok) == 3 and all(len(r.sequences_ids) == 10 for r in ok)
+    ref = model.generate(e, [prompt] * 3, beam_size=5, max_length=len(prompt) + 8, return_scores=True)
+    assert all(len(r.sequences_ids[0]) >= 1 for r in ref)
+
+
+def test_set_decode_batch_while_callers_arrive():
+    """fw_model_set_decode_batch rebuilds the pool, the run workspaces and the second lane: refused while runs are queued or
+    in flight, and a generate() that arrives DURING a rebuild waits for it instead of reading half-built state (ADVICE
+    round 3: the rebuild used to drop the group lock before it touched lane1)"""
+    from faster_whisper_amd import _lib
+    cfg, model = _model("micro", 4)
+    lib = _lib.load()
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    kw = dict(beam_size=5, max_length=len(prompt) + 6, return_scores=True)
+    batch = _batches(1, 3)[0]
+    ref = model.generate(model.encode_pcm(batch), [prompt] * 3, **kw)
+    primary = model._replicas[0].handle
+    stop = threading.Event()
+    errs, n_ok = [], [0]
+
+    def caller():
+        try:
+            while not stop.is_set():
+                r = model.generate(model.encode_pcm(batch), [prompt] * 3, **kw)
+                assert [x.sequences_ids for x in r] == [x.sequences_ids for x in ref]
+                n_ok[0] += 1
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=caller) for _ in range(3)]
+    for t in ts:
+        t.start()
+    n_done = n_refused = 0
+    for i in range(40):                                   # resize back and forth between one lane and two
+        rc = lib.fw_model_set_decode_batch(primary, 12 if i % 2 else 6)
+        n_done += rc == 0
+        n_refused += rc != 0
+    stop.set()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    print(f"resizes applied {n_done}, refused while busy {n_refused}, generate calls served {n_ok[0]}")
+    assert n_ok[0] > 0 and n_done + n_refused == 40
