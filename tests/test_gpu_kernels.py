@@ -138,8 +138,20 @@ def test_encoder_attention(model, B, H, T, scale):
     p /= p.sum(-1, keepdims=True)
     ref = (p @ vh).transpose(0, 2, 1, 3).reshape(B, T, d)
     err = np.abs(out - ref).max()
-    print(f"attention B={B} H={H} T={T} scale={scale}: abs err {err:.2e}")
-    assert np.isfinite(out).all() and err < 5e-3
+    # the kernel's one documented rounding point ahead of the MFMAs: Q' = fp16(q * log2(e) / 8), scores in the exp2 domain.
+    # With scores of standard deviation 9 (scale 3) that rounding alone moves a near-tied pair of keys by 7e-3 of output
+    # (numpy: fp64 with Q' against fp64 with q = 7.29e-3), so the large-score case is held against the reference WITH it
+    qs = _h((q * (0.125 * 1.4426950408889634)).astype(np.float32)).reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    s2 = qs @ kh.transpose(0, 1, 3, 2)
+    s2 -= s2.max(-1, keepdims=True)
+    p2 = np.exp2(s2)
+    p2 /= p2.sum(-1, keepdims=True)
+    ref2 = (p2 @ vh).transpose(0, 2, 1, 3).reshape(B, T, d)
+    err2 = np.abs(out - ref2).max()
+    print(f"attention B={B} H={H} T={T} scale={scale}: abs err {err:.2e} (fp64), {err2:.2e} (fp64 with the kernel's fp16 Q')")
+    assert np.isfinite(out).all() and err2 < 3e-3
+    if scale <= 1:
+        assert err < 5e-3
 
 
 # ---- decoder-step linears: the fragment-major register-streaming GEMM exactly as a decode step launches it ----
