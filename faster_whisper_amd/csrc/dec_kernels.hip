@@ -739,7 +739,9 @@ static __device__ __forceinline__ float sum8_dpp(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
   return v;
 }
-__global__ __launch_bounds__(1024) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
+// (8 waves per SIMD: the kernel waits on memory 70 % of its wave cycles (profiles/r03_pmc_sq.json) with 70 registers = 7
+//  waves; at 55 registers it spills nothing and a CU holds six (head, chunk) workgroups of five beams instead of five)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void dec_self_attn_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
                                                              half_t* __restrict__ vc, int n_ctx, int cache_ctx,
                                                              int H, const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
                                                              half_t* __restrict__ out, const int* __restrict__ d_step,

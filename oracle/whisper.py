@@ -59,6 +59,11 @@ class GenResult:
     # teacher forcing (force_tokens, greedy): per step, log-prob of the best token minus log-prob of the FORCED token
     # (0 where the forced token is the arg-max): how far every choice of a given sequence is from greedy-optimal
     forced_gaps: List[float] = field(default_factory=list)
+    # greedy / teacher forcing with timestamps: per step, log(timestamp mass) - max text log-prob — the quantity whose
+    # SIGN decides timestamp rule (e) (text forbidden when the timestamps together outweigh the best text token).  A step
+    # where it is within the numerical noise is a tied RULE: engine and oracle may renormalise differently there, and the
+    # log-prob of the very same token differs by log(timestamp mass); nan where the rule does not apply
+    rule_margins: List[float] = field(default_factory=list)
 
 
 @dataclass
@@ -348,8 +353,12 @@ class OracleWhisper:
                     lg[tb + max_initial_timestamp_index + 1:] = NEG
             lp = _log_softmax(lg)
             ts_lp = _logsumexp(lp[tb:])
-            if ts_lp > lp[:tb].max():
+            text_max = lp[:tb].max()
+            self._rule_margin = float(ts_lp - text_max) if np.isfinite(ts_lp) and np.isfinite(text_max) else float("nan")
+            if ts_lp > text_max:
                 lg[:tb] = NEG
+        else:
+            self._rule_margin = float("nan")
         return _log_softmax(lg)
 
     # ------------------------------------------------------------------ generate
@@ -485,12 +494,13 @@ class OracleWhisper:
 
     def _greedy(self, cache, ckv1, logits, proc, P, budget, lp_pow, no_speech, forced, sample=None):
         c = self.cfg
-        gen, margins, gaps = [], [], []
+        gen, margins, gaps, rule_margins = [], [], [], []
         cum = np.float32(0.0)
         step = 0
         ended = False
         while step < budget:
             lp = proc(logits[0], gen)
+            rule_margins.append(getattr(self, "_rule_margin", float("nan")))
             if sample is not None:   # Gumbel-max draw from softmax(lp / T); the score keeps the plain lp
                 seed, row, inv_t = sample
                 key = np.where(np.isfinite(lp), lp * np.float32(inv_t) + _gumbel(seed, row, step, lp.shape[0]),
@@ -515,7 +525,7 @@ class OracleWhisper:
             h = self.decoder_step(torch.tensor([tok]), P - 1 + step, cache, ckv1)
             logits = self.logits(h).numpy()
         score = _hyp(cum, gen, lp_pow)[0]
-        return GenResult([gen], [float(score)], no_speech, margins, gaps)
+        return GenResult([gen], [float(score)], no_speech, margins, gaps, rule_margins)
 
     # ------------------------------------------------------------------ detect_language
     def detect_language(self, enc: np.ndarray):

@@ -216,12 +216,20 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48, long_steps=0, logits_r
     names = language_token_strings(cfg)
     gl = model.detect_language(enc)
     rl = oracle.detect_language(sub)
+    rlf = None
+    if not i8:     # information: the oracle in the engine's own evaluation order (LayerNorms folded), like the tf figure above
+        oracle.fold_ln = True
+        rlf = oracle.detect_language(sub)
+        oracle.fold_ln = False
     for j, b in enumerate(SUBSET):
         gp = dict(gl[b])
         worst = max(abs(gp[names[tid - cfg.lang_begin]] - p) for tid, p in rl[j])
         expect(worst < tol["lang"], f"language probabilities chunk {b}: max diff {worst:.2e}")
         print(f"{tag} chunk {b}: detect_language top {gl[b][0]} vs {(names[rl[j][0][0] - cfg.lang_begin], rl[j][0][1])}, "
               f"max prob diff {worst:.2e}")
+        if rlf is not None:
+            wf = max(abs(gp[names[tid - cfg.lang_begin]] - p) for tid, p in rlf[j])
+            print(f"{tag} chunk {b}:   against the folded order: max prob diff {wf:.2e}")
 
     # ---- align (word timestamps) on the greedy tokens ----
     text = [[t for t in g.sequences_ids[0] if t < cfg.eot] for g in g1]
