@@ -56,6 +56,12 @@ EXCEPTIONS = {
     # (a softmax over 100 ids with a 0.6 top probability: dp = p (1 - p) dlogit, 5e-3 <-> 2e-2 of logit)
     ("large-v3 float16", "lang"): (6e-3, 5.2e-3, FP16_ORDER),
     ("large-v3 float16", "align"): (4e-3, 2.0e-3, FP16_ORDER),
+    # round 4: 7.3e-4 / 1.5e-4 until the encoder attention's softmax changed its rounding (denominator from the fp16 P
+    # values), then 1.57e-3 / 6.6e-4 on the new encoder output.  Cause, measured: the decoder LayerNorm fold.  The oracle in
+    # the engine's own order (fold_ln) against the oracle in the explicit order, CPU alone, this chunk: 1.59e-3
+    # (DESIGN.md section 5); the engine against the folded-order oracle: 9.4e-4 / 1.8e-4 (printed by the test).  With two
+    # decoder layers nothing averages the fold's rounding out; large-v3's 32 layers scatter all orders alike (ln_unfold probe)
+    ("distil-large-v3 float16", "lang"): (3e-3, 1.57e-3, "LayerNorm-folded fp16 order vs the oracle's explicit order"),
     ("large-v3 int8_float16", "tf"): (2e-2, 1.0e-2, INT8_CODES),
     ("large-v3 int8_float16", "beam"): (1e-2, 3.7e-3, INT8_CODES),
     ("large-v3 int8_float16", "lang"): (6e-2, 3.8e-2, INT8_CODES),
