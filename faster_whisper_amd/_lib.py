@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FWAMD_LIB: another build of the library (A/B of two builds on one GPU box: profiles/r04_ab_builds.sh); the product
+# FWAMD_LIB: another build of the library (A/B of two builds on one GPU box: profiles/calls/r04_ab_builds.sh); the product
 # loads the in-tree libfwamd.so
 LIB_PATH = os.environ.get("FWAMD_LIB") or os.path.join(_HERE, "libfwamd.so")
 
