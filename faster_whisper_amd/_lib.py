@@ -77,6 +77,7 @@ SYMBOLS = [
     "fw_dev_alloc", "fw_dev_free", "fw_dev_upload",
     "fw_test_gemm", "fw_test_layernorm", "fw_test_attention", "fw_test_dec_linear", "fw_test_dec_logits", "fw_test_logits_rules", "fw_bench_gemm", "fw_bench_dec_linear", "fw_bench_attention",
     "fw_vad_create", "fw_vad_forward", "fw_vad_free", "fw_vad_forward_dev",
+    "fw_flac_info", "fw_flac_decode",
 ]
 
 _lib = None
@@ -113,6 +114,9 @@ def load():
     lib.fw_model_run_capacity.argtypes = [vp]
     lib.fw_model_run_capacity.restype = i32
     lib.fw_dec_big_min_rows.restype = i32
+    if hasattr(lib, "fw_flac_info"):
+        lib.fw_flac_info.argtypes = [vp, i64, i32p, i32p, i32p, i64p]
+        lib.fw_flac_decode.argtypes = [vp, i64, vp, i64, i64p, i32p]
     if hasattr(lib, "fw_test_knob"):          # (absent from the older build an A/B loads through FWAMD_LIB)
         lib.fw_test_knob.argtypes = [i32, i32]
     lib.fw_model_join_decoder.argtypes = [vp, vp]

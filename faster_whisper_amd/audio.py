@@ -4,7 +4,10 @@ Mirrors `faster_whisper/audio.py:19-76` (`decode_audio(input_file, sampling_rate
 the reference decodes with PyAV (bundled FFmpeg), resamples to signed 16-bit at the target rate and returns
 `int16 / 32768` as float32 (mono, or a (left, right) pair with `split_stereo`).  Here:
   * RIFF/WAVE files (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) are read natively;
-  * other containers are delegated to PyAV when it is importable, and fail loudly otherwise;
+  * FLAC streams are decoded natively by libfwamd (`fw_flac_decode`, csrc/flac_host.cpp: every frame CRC-checked, the
+    decoded PCM checked against the MD5 signature the encoder stored — the reference's own tests/data/jfk.flac decodes
+    bit-exactly);
+  * other containers (MP3, AAC, Ogg ...) are delegated to PyAV when it is importable, and fail loudly otherwise;
   * rate conversion is a Kaiser-windowed sinc polyphase filter in numpy (libswresample is not available, so the
     resampled waveform is not bit-identical to the reference's — the s16 quantisation step and the interface are).
 `pad_or_trim` (audio.py:111-123) lives in transcribe.py.
@@ -59,6 +62,25 @@ def _read_wav(data: bytes) -> Tuple[np.ndarray, int]:
         raise ValueError(f"unsupported WAVE format code {code} (only PCM and IEEE float are read natively)")
     n = len(x) // channels
     return x[:n * channels].reshape(n, channels), rate
+
+
+def _read_flac(data: bytes) -> Tuple[np.ndarray, int]:
+    """-> (float32 [frames, channels] in [-1, 1), sample rate); raises ValueError on a corrupt stream (CRC / MD5)"""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    rate, ch, bps, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    _lib.check(lib.fw_flac_info(buf, len(data), C.byref(rate), C.byref(ch), C.byref(bps), C.byref(total)))
+    # an unknown length (streamed encode) is bounded by the data: a sample costs at least one bit per channel
+    cap = total.value if total.value > 0 else 8 * len(data)
+    out = np.zeros((cap, ch.value), dtype=np.int32)
+    n, md5 = C.c_int64(), C.c_int32()
+    _lib.check(lib.fw_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(md5)))
+    if md5.value == 0:
+        raise ValueError("FLAC: the decoded audio does not carry the MD5 signature stored in the stream (corrupt file)")
+    x = (out[:n.value].astype(np.float64) / float(1 << (bps.value - 1))).astype(np.float32)
+    return x, rate.value
 
 
 def resample(x: np.ndarray, rate_in: int, rate_out: int, taps_per_phase: int = 32, beta: float = 9.0) -> np.ndarray:
@@ -128,8 +150,13 @@ def decode_audio(input_file: Union[str, BinaryIO], sampling_rate: int = 16000, s
         data = input_file
     else:
         data = input_file.read()
+    native = None
     if data[:4] == b"RIFF" and data[8:12] == b"WAVE":
-        x, rate = _read_wav(data)
+        native = _read_wav(data)
+    elif data[:4] == b"fLaC" or (data[:3] == b"ID3" and b"fLaC" in data[:1 << 20]):
+        native = _read_flac(data)
+    if native is not None:
+        x, rate = native
         if split_stereo:
             if x.shape[1] < 2:
                 x = np.repeat(x[:, :1], 2, axis=1)
@@ -140,6 +167,6 @@ def decode_audio(input_file: Union[str, BinaryIO], sampling_rate: int = 16000, s
     try:
         import av  # noqa: F401
     except ImportError as e:
-        raise RuntimeError("only RIFF/WAVE files are decoded natively; other containers need the PyAV package "
+        raise RuntimeError("only RIFF/WAVE and FLAC are decoded natively; other containers need the PyAV package "
                            "(the reference's decoder), which is not installed") from e
     return _decode_with_pyav(io.BytesIO(data), sampling_rate, split_stereo)

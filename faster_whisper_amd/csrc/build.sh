@@ -22,6 +22,11 @@ if [ ! -f build/vad_host.o ] || [ vad_host.cpp -nt build/vad_host.o ] || [ ../..
   g++ -O3 -std=c++17 -fPIC -Wall -c vad_host.cpp -o build/vad_host.o &
   pids+=($!)
 fi
+# host-only C++: the native FLAC decoder of the audio front (row f-4)
+if [ ! -f build/flac_host.o ] || [ flac_host.cpp -nt build/flac_host.o ] || [ ../../include/fwamd.h -nt build/flac_host.o ]; then
+  g++ -O2 -std=c++17 -fPIC -Wall -c flac_host.cpp -o build/flac_host.o &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -pthread build/*.o -o $OUT
 echo "built $(realpath $OUT)"

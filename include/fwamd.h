@@ -316,6 +316,18 @@ void fw_vad_free(fw_vad* v);
 int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows, int64_t n, float* h, float* c,
                            float* probs);
 
+/* ---- audio front: native FLAC decoding --------------------------------------------
+ * The reference decodes every container through PyAV / FFmpeg (faster_whisper/audio.py:19-76); its own test asset
+ * (tests/data/jfk.flac) is FLAC.  fw_flac_info reads STREAMINFO (total_samples is per channel, 0 = unknown);
+ * fw_flac_decode decodes the whole stream (host code, csrc/flac_host.cpp) into interleaved int32 samples
+ * out[sample][channel] (capacity_samples per channel), verifying every frame's CRC-8 / CRC-16, and reports in md5_status
+ * whether the decoded PCM carries the MD5 signature the encoder stored: 1 = yes (bit-exact decode), 0 = no, -1 = nothing
+ * to compare with (no signature, or a truncated stream: the whole frames present are returned). */
+int32_t fw_flac_info(const uint8_t* data, int64_t n_bytes, int32_t* sample_rate, int32_t* channels,
+                     int32_t* bits_per_sample, int64_t* total_samples);
+int32_t fw_flac_decode(const uint8_t* data, int64_t n_bytes, int32_t* out, int64_t capacity_samples,
+                       int64_t* n_decoded, int32_t* md5_status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,8 +67,10 @@ def test_other_sample_formats():
     assert np.abs(decode_audio(_wav_raw(1, 8, 16000, 1, u8.tobytes())) - x).max() < 0.01
     with pytest.raises(ValueError):
         decode_audio(_wav_raw(2, 4, 16000, 1, b"\x00" * 8))                      # ADPCM: not read natively
+    with pytest.raises(ValueError, match="FLAC"):
+        decode_audio(b"fLaC" + b"\x00" * 64)                                     # FLAC is read natively: a corrupt one says so
     with pytest.raises(RuntimeError, match="PyAV"):
-        decode_audio(b"fLaC" + b"\x00" * 64)                                     # other containers need PyAV
+        decode_audio(b"OggS" + b"\x00" * 64)                                     # other containers need PyAV
 
 
 @pytest.mark.parametrize("rate", [48000, 44100, 22050, 8000])
