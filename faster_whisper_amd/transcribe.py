@@ -366,7 +366,7 @@ class WhisperModel:
                                 "True; setting to False instead.")
             multilingual = False
         if not isinstance(audio, np.ndarray):
-            from .audio import decode_audio   # path / file object: WAVE natively, other containers through PyAV
+            from .audio import decode_audio   # path / file object: WAVE and FLAC natively, other containers through PyAV
             audio = decode_audio(audio, sampling_rate=sr)
         duration = audio.shape[0] / sr
         duration_after_vad = duration
@@ -862,7 +862,7 @@ class BatchedInferencePipeline:
                              "True; setting to False instead.")
             multilingual = False
         if not isinstance(audio, np.ndarray):
-            from .audio import decode_audio   # path / file object: WAVE natively, other containers through PyAV
+            from .audio import decode_audio   # path / file object: WAVE and FLAC natively, other containers through PyAV
             audio = decode_audio(audio, sampling_rate=sr)
         audio = np.asarray(audio, dtype=np.float32)
         duration = audio.shape[0] / sr

@@ -170,3 +170,28 @@ def test_empty_audio(wm):
     assert list(segs) == [] and info.duration == 0.0
     lang, prob, all_probs = model.detect_language(audio)
     assert lang in model.supported_languages and 0.0 < prob <= 1.0 and len(all_probs) == cfg.n_langs
+
+
+def test_transcribe_reads_flac_files(wm):
+    """the reference accepts a path (transcribe.py:278, decode_audio): a FLAC file goes through the native decoder
+    (csrc/flac_host.cpp) and must give exactly what the decoded waveform gives when it is passed as an array"""
+    import os
+    from conftest import GOLDEN
+    from faster_whisper_amd.audio import decode_audio
+    from faster_whisper_amd.transcribe import BatchedInferencePipeline
+    cfg, w, model = wm
+    path = os.path.join(GOLDEN, "flac_jfk_head.flac")      # 0.84 s of the reference's jfk.flac (44.1 kHz stereo 24 bit)
+    wave = decode_audio(path)
+    assert wave.dtype == np.float32 and wave.shape == (13375,)
+    pipe = BatchedInferencePipeline(model)
+    kw = dict(language="en", beam_size=2, batch_size=2, clip_timestamps=[{"start": 0.0, "end": len(wave) / 16000.0}],
+              max_new_tokens=10)
+    a, ia = pipe.transcribe(path, **kw)
+    b, ib = pipe.transcribe(wave, **kw)
+    a, b = list(a), list(b)
+    assert len(a) == len(b) >= 1 and ia.duration == ib.duration == pytest.approx(13375 / 16000.0)
+    for x, y in zip(a, b):
+        assert x.tokens == y.tokens and x.avg_logprob == y.avg_logprob and (x.start, x.end) == (y.start, y.end)
+    with open(path, "rb") as f:                            # file objects too
+        c, _ = model.transcribe(f, language="en", beam_size=1, max_new_tokens=6)
+        assert len(list(c)) >= 1
