@@ -8,9 +8,9 @@
 //   [N,576] -> reflect pad 128|128 -> conv basis[258][256] stride 128, frame 0 dropped -> |.| [129][4]
 //   -> conv 129->128 k3 s1 -> conv 128->64 k3 s2 -> conv 64->64 k3 s2 -> conv 64->128 k3 s1 (ReLU each, zero pad 1)
 //   -> LSTM(128, hidden 128; ONNX gate order i,o,f,c; the N windows are the sequence) -> ReLU -> 128->1 -> sigmoid
-// A GPU version (one persistent workgroup for the recurrence) is the MI355X-first design for this row; it is
-// not built yet — one hour of audio is 112 500 windows = 0.16 TFLOP, which this host path does in well under
-// a second of wall time on the box's cores.
+// The device version (csrc/vad.hip, fw_vad_forward_dev: one workgroup per window + one persistent workgroup for the
+// recurrence) exists and is tested against this one; the Python front uses this host path by default, as the reference
+// runs the VAD on the CPU — one hour of audio is 112 500 windows = 0.16 TFLOP, well under a second on the box's cores.
 #include <math.h>
 #include <string.h>
 

@@ -356,8 +356,8 @@ class WhisperModel:
                    vad_speech_probs=None):
         """Sequential (seek-loop) transcription: 30 s windows decoded one after the other, each conditioned on
         the text before it, with the temperature-fallback ladder.  Same arguments / defaults / return value
-        as the reference's WhisperModel.transcribe; `vad_speech_probs` feeds vad.get_speech_timestamps while
-        the Silero network (row f-3) is not built."""
+        as the reference's WhisperModel.transcribe; `vad_speech_probs` (not in the reference) feeds
+        vad.get_speech_timestamps with precomputed window probabilities instead of running the Silero network."""
         from .vad import VadOptions, collect_chunks, get_speech_timestamps
         from .words import restore_speech_timestamps
         sr = self.feature_extractor.sampling_rate
