@@ -79,10 +79,10 @@ def frag_unperm(t, ke=32):
     return t.reshape(-1)[off.reshape(-1)].reshape(n_rows, k_cols)
 
 
-def forced_score(oracle, enc_np_b, prompt, ids, kw):
-    """the oracle's score of a GIVEN token sequence under the same decoding rules (teacher forcing through its
-    greedy path): cum log-prob / len^length_penalty exactly as a finished hypothesis is scored.  A sequence shorter
-    than the budget ended with <eot>."""
+def forced_result(oracle, enc_np_b, prompt, ids, kw):
+    """the oracle teacher-forced along a GIVEN token sequence under the same decoding rules (its greedy path): the
+    GenResult (score = cum log-prob / len^length_penalty exactly as a finished hypothesis is scored, no-speech
+    probability, margins).  A sequence shorter than the budget ended with <eot>."""
     from oracle.whisper import max_new_tokens
     budget = max_new_tokens(kw.get("max_length", 448), len(prompt))
     forced = list(ids) + ([oracle.cfg.eot] if len(ids) < budget else [])
@@ -90,6 +90,12 @@ def forced_score(oracle, enc_np_b, prompt, ids, kw):
     r = oracle.generate(enc_np_b[None] if enc_np_b.ndim == 2 else enc_np_b, [list(prompt)], beam_size=1,
                         force_tokens=[forced], **k2)[0]
     assert r.sequences_ids[0] == list(ids), (r.sequences_ids[0], ids)
+    return r
+
+
+def forced_score(oracle, enc_np_b, prompt, ids, kw):
+    """the oracle's score of a GIVEN token sequence (forced_result above)"""
+    r = forced_result(oracle, enc_np_b, prompt, ids, kw)
     forced_score.rule_margins = [m for m in (r.rule_margins or []) if m == m]     # (of the last call; nan = rule not applicable)
     return r.scores[0]
 
