@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const half_t* __restrict_
     // raises its own reference to its own maximum, which is always allowed)
     if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > AE_LAG) != 0) {
       const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      // (first tile: lsum and o are still zero and delta may have any sign — a first tile whose scores all lie below
+      // -128 would make exp2(-delta) infinite and 0 x inf = NaN; nothing is rescaled there)
+      const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
       m_ref += delta;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { cneg[r] = -m_ref; lsum[r] *= alpha; }

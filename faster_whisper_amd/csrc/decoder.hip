@@ -210,7 +210,16 @@ static void pool_release(CrossPool* p, const std::vector<int>& blk) {
 struct PoolHold {   // releases its blocks when the decode run / detect_language / align call ends, however it ends
   CrossPool* p;
   std::vector<int> blk;
-  ~PoolHold() { if (p) pool_release(p, blk); }
+  hipStream_t st = nullptr;   // the stream the blocks' projections / readers were launched on
+  // A block carries its encoder output's id from the moment the projection is LAUNCHED; the other lane (another stream)
+  // may take it as a hit, or recycle it, as soon as it is released.  Every normal return path has synchronised the stream
+  // already (this wait then costs nothing); an error return taken earlier must not free blocks that kernels of this
+  // stream may still be writing.
+  ~PoolHold() {
+    if (!p) return;
+    if (st && !blk.empty()) (void)hipStreamSynchronize(st);
+    pool_release(p, blk);
+  }
 };
 
 static int gen_workspace_build(Model* m) {
@@ -588,7 +597,7 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   // ---- the run's blocks of the cross-attention pool (all at once), the projection of those that are not there yet,
   //      and the run's chunk -> pool slot table ----
   CrossPool* pool = pool_of(m);
-  PoolHold hold{pool, {}};
+  PoolHold hold{pool, {}, st};
   std::vector<int> slot_host((size_t)Bx);
   {
     std::vector<uint64_t> ids;
@@ -1056,7 +1065,7 @@ int32_t fw_detect_language(fw_model* fm, const fw_tensor* enc_t, int32_t B, int3
   GenWorkspace* g = m->gen;
   hipStream_t st = m->dec_stream;
   CrossPool* pool = pool_of(m);
-  PoolHold hold{pool, {}};
+  PoolHold hold{pool, {}, st};
   std::vector<int> slots(B);
   {
     std::vector<char> hit;
@@ -1257,7 +1266,7 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
   GenWorkspace* g = m->gen;
   hipStream_t st = m->dec_stream;
   CrossPool* pool = pool_of(m);
-  PoolHold hold{pool, {}};
+  PoolHold hold{pool, {}, st};
   std::vector<int> slots(B);
   {
     std::vector<char> hit;

@@ -73,7 +73,7 @@ struct LinearW {           // y = x W^T + b ; W [N][K] fp16 (or int8 + per-row s
 struct LNW { const half_t* g = nullptr; const half_t* b = nullptr; };
 
 struct EncLayerW { LNW ln1, ln2; LinearW qk, v, out, ffn1, ffn2; };
-// fp16: qkv, cq, ffn1 are LN-folded; the blob also carries the plain weights (qkv_p, cq_p, ffn1_p) and ln1/2/3 for the
+// fp16: qkv, cq, ffn1 are LN-folded; a blob packed with FWAMD_LN_UNFOLD also carries the plain weights (qkv_p, cq_p, ffn1_p) and ln1/2/3 for the
 // explicit-LayerNorm evaluation (Model::ln_unfold); int8_float16: explicit LayerNorms feeding the quantiser
 struct DecLayerW { LNW ln1, ln2, ln3; LinearW qkv, out, cq, ck, cv, cout, ffn1, ffn2; LinearW qkv_p, cq_p, ffn1_p; };
 
@@ -149,8 +149,10 @@ struct Model {
   // fp16 evaluation order of the decoder LayerNorms.  0: folded into the consuming linear (one
   // launch fewer per LayerNorm; W o g is rounded to fp16 once more and the normalised row is never rounded); 1: the final
   // LayerNorm is its own kernel — fp16(LN(x)) times the tied embedding, the rounding points of the reference's fp16
-  // path; 2: every decoder LayerNorm is.  FWAMD_LN_UNFOLD at model creation; fw_model_set_ln_unfold.
+  // path; 2: every decoder LayerNorm is.  FWAMD_LN_UNFOLD in the environment when the blob is PACKED (the plain weight
+  // forms then travel in it: has_plain) and when the model is created.  A diagnostic; default off.
   int ln_unfold = 0;
+  bool has_plain = false;
 
   // log-mel constants
   float* lm_consts = nullptr;  // cos table [400] + hann [400]

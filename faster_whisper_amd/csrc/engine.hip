@@ -311,11 +311,16 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     return add_plain(base + ".b", {N});
   };
   // a decoder linear fed by a LayerNorm: folded in fp16 mode; explicit LN (quantised output) in int8 mode
+  // FWAMD_LN_UNFOLD (a diagnostic, default off: DESIGN.md section 5) set at PACK time: the fp16 blob then also carries
+  // the plain weights + LayerNorms of qkv / cross.q / ffn1 / the vocabulary projection (+1 GB at large-v3) for the
+  // explicit-LayerNorm evaluation order; without it only the folded forms travel
+  const char* lu_env = getenv("FWAMD_LN_UNFOLD");
+  const char* pp_env = getenv("FWAMD_PACK_PLAIN");   // (the probe packs once and creates models in all three orders)
+  const bool with_plain = (lu_env && (lu_env[0] == '1' || lu_env[0] == '2') && !lu_env[1]) || (pp_env && pp_env[0] == '1');
   auto add_ln_linear = [&](const std::string& base, const std::string& ln, int N, int K) -> int {
     if (!i8) {
-      // both evaluation orders travel in the blob: the folded form and the plain weight + LayerNorm (Model::ln_unfold)
       int rc = add_folded(base, base + ".w", base + ".b", ln + ".g", ln + ".b", N, K);
-      if (rc) return rc;
+      if (rc || !with_plain) return rc;
     }
     int rc = add_linear(base, N, K);
     if (rc) return rc;
@@ -368,10 +373,12 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
     TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
   } else {
     TRY(add_folded("dec.logits", "dec.tok_emb", "", "dec.ln.g", "dec.ln.b", cfg->n_vocab, d));
-    // the explicit order: final LayerNorm as a kernel, then the tied embedding itself (fragment-major copy)
-    TRY(add_plain("dec.tok_emb", {cfg->n_vocab, d}));
-    items.back().name = "dec.logits.wp";
-    TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
+    if (with_plain) {
+      // the explicit order: final LayerNorm as a kernel, then the tied embedding itself (fragment-major copy)
+      TRY(add_plain("dec.tok_emb", {cfg->n_vocab, d}));
+      items.back().name = "dec.logits.wp";
+      TRY(add_plain("dec.ln.g", {d})); TRY(add_plain("dec.ln.b", {d}));
+    }
   }
 #undef TRY
 
@@ -443,8 +450,9 @@ static int pack_blob(const fw_config* cfg, const fw_weight* w, int nw, int compu
   h.n_tensors = (int32_t)items.size();
   h.total_bytes = off;
   h.compute_type = compute_type;
-  h.reserved = 5;   // layout generation: 4 = decoder linears and the vocabulary projection fragment-major; 5 = fp16
-                    // blobs carry the plain (LayerNorm-explicit) forms of qkv / cross.q / ffn1 / logits next to the folded ones
+  h.reserved = 6;   // layout generation: 4 = decoder linears and the vocabulary projection fragment-major; 5 = fp16
+                    // blobs carry the plain (LayerNorm-explicit) forms of qkv / cross.q / ffn1 / logits next to the folded
+                    // ones; 6 = only when packed with FWAMD_LN_UNFOLD set
   h.cfg = *cfg;
   memcpy(blob.data(), &h, sizeof(h));
   memcpy(blob.data() + sizeof(h), entries.data(), entries.size() * sizeof(BlobEntry));
@@ -590,6 +598,7 @@ static int bind_weights(Model* m) {
   TRY(ln("enc.ln_post", &m->enc_ln_post));
   TRY(need("dec.tok_emb", &m->tok_emb)); TRY(need("dec.pos", &m->dec_pos));
   m->dec.resize(c.n_dec_layers);
+  m->has_plain = !i8 && tptr(m, "dec.logits.wp") != nullptr;
   for (int i = 0; i < c.n_dec_layers; ++i) {
     DecLayerW& L = m->dec[i];
     auto nm = [&](const char* s) { snprintf(nb, sizeof(nb), "dec.%d.%s", i, s); return std::string(nb); };
@@ -602,10 +611,12 @@ static int bind_weights(Model* m) {
       TRY(folded(nm("self.qkv"), &L.qkv, 3 * d, d));
       TRY(folded(nm("cross.q"), &L.cq, d, d));
       TRY(folded(nm("ffn1"), &L.ffn1, 4 * d, d));
-      TRY(ln(nm("ln1"), &L.ln1)); TRY(ln(nm("ln2"), &L.ln2)); TRY(ln(nm("ln3"), &L.ln3));
-      TRY(linear(nm("self.qkv"), &L.qkv_p, 3 * d, d, 0));
-      TRY(linear(nm("cross.q"), &L.cq_p, d, d, 0));
-      TRY(linear(nm("ffn1"), &L.ffn1_p, 4 * d, d, 0));
+      if (m->has_plain) {   // packed with FWAMD_LN_UNFOLD: the explicit-LayerNorm forms travel too
+        TRY(ln(nm("ln1"), &L.ln1)); TRY(ln(nm("ln2"), &L.ln2)); TRY(ln(nm("ln3"), &L.ln3));
+        TRY(linear(nm("self.qkv"), &L.qkv_p, 3 * d, d, 0));
+        TRY(linear(nm("cross.q"), &L.cq_p, d, d, 0));
+        TRY(linear(nm("ffn1"), &L.ffn1_p, 4 * d, d, 0));
+      }
     }
     TRY(linear(nm("self.out"), &L.out, d, d, 0));
     TRY(linear(nm("cross.kv"), &L.ck, d, d, 0));
@@ -624,9 +635,11 @@ static int bind_weights(Model* m) {
   } else {
     TRY(folded("dec.logits", &m->logits, c.n_vocab, d));
     m->logits_p = LinearW();
-    TRY(need("dec.logits.wp", &m->logits_p.w));
-    m->logits_p.N = c.n_vocab; m->logits_p.K = d;
-    TRY(ln("dec.ln", &m->dec_ln));
+    if (m->has_plain) {
+      TRY(need("dec.logits.wp", &m->logits_p.w));
+      m->logits_p.N = c.n_vocab; m->logits_p.K = d;
+      TRY(ln("dec.ln", &m->dec_ln));
+    }
   }
 #undef TRY
   return FW_OK;
@@ -687,9 +700,9 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   Model* m = &fm->impl;
   m->cfg = h.cfg;
   m->compute_type = h.compute_type;
-  if (h.reserved != 5) {
+  if (h.reserved != 6) {
     delete fm;
-    set_error("weight blob was packed by an older libfwamd (layout generation %d, expected 5): repack it", h.reserved);
+    set_error("weight blob was packed by an older libfwamd (layout generation %d, expected 6): repack it", h.reserved);
     return FW_EINVAL;
   }
   m->device = device;
@@ -717,6 +730,11 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   {
     const char* lu = getenv("FWAMD_LN_UNFOLD");   // fp16 evaluation order of the decoder LayerNorms (engine.h)
     if (lu && lu[0] >= '0' && lu[0] <= '2' && !lu[1]) m->ln_unfold = lu[0] - '0';
+    if (m->ln_unfold && m->compute_type != FW_COMPUTE_INT8_FLOAT16 && !m->has_plain) {
+      set_error("FWAMD_LN_UNFOLD=%d needs a weight blob packed with FWAMD_LN_UNFOLD set (this one carries the folded forms only)",
+                m->ln_unfold);
+      return fail(FW_EINVAL);
+    }
   }
   if (!decoder_lane) {   // (a decode lane has no front end and no encoder: weights, a stream, a decode workspace)
     if ((rc = setup_logmel_consts(m))) return fail(rc);

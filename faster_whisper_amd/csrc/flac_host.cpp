@@ -97,19 +97,20 @@ uint8_t crc8(const uint8_t* p, size_t n) {
   }
   return c;
 }
-uint16_t crc16(const uint8_t* p, size_t n) {
-  static uint16_t tab[256];
-  static bool init = false;
-  if (!init) {
+struct Crc16Table {
+  uint16_t t[256];
+  Crc16Table() {
     for (int i = 0; i < 256; ++i) {
       uint16_t c = (uint16_t)(i << 8);
       for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1);
-      tab[i] = c;
+      t[i] = c;
     }
-    init = true;
   }
+};
+uint16_t crc16(const uint8_t* p, size_t n) {
+  static const Crc16Table tab;   // magic static: initialised once, thread-safe (decode workers may race to their first frame)
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ tab[(c >> 8) ^ p[i]]);
+  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ tab.t[(c >> 8) ^ p[i]]);
   return c;
 }
 

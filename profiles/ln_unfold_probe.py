@@ -31,6 +31,7 @@ def main():
     prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
     sup = [cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe]
     names = language_token_strings(cfg)
+    os.environ["FWAMD_PACK_PLAIN"] = "1"     # the blob carries the plain weight forms too (opt-in since round 5)
     for order in (0, 1, 2):
         os.environ["FWAMD_LN_UNFOLD"] = str(order)
         model = Whisper(f"synthetic:{name}", device="cuda", files={"config": cfg, "weights": w}, compute_type="float16",

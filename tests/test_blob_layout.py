@@ -13,11 +13,17 @@ def _h(a):
     return np.asarray(a, dtype=np.float32).astype(np.float16)
 
 
-def test_fragment_major_decoder_linears():
+def test_fragment_major_decoder_linears(monkeypatch):
     cfg = get_config("micro")
     w = synthetic_weights(cfg, seed=4)
+    h0, t0 = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_FLOAT16))
+    # the default blob carries the folded forms only (layout generation 6): no plain qkv / cross.q / ffn1 weights, no
+    # second copy of the tied embedding (+1 GB at large-v3 for a default-off diagnostic otherwise)
+    assert h0.reserved == 6
+    assert "dec.0.self.qkv.wf" in t0 and "dec.0.self.qkv.w" not in t0 and "dec.logits.wp" not in t0 and "dec.1.ln3.g" not in t0
+    monkeypatch.setenv("FWAMD_PACK_PLAIN", "1")
     h, t = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_FLOAT16))
-    assert h.reserved == 5
+    assert h.reserved == 6 and all(np.array_equal(t[k], t0[k]) for k in t0)
     for name in ("dec.0.self.out.w", "dec.1.cross.out.w", "dec.0.ffn2.w"):
         assert np.array_equal(t[name], frag_perm(_h(w[name]))), name
     # LayerNorm-folded ones: (W * g) rounded to fp16, then permuted; s1 / cf stay plain
@@ -35,7 +41,7 @@ def test_fragment_major_decoder_linears():
     un = frag_unperm(t["dec.logits.wf"])
     assert np.array_equal(un[:V], lg) and not un[V:].any()
     assert t["dec.logits.s1"].shape == (V,)
-    # layout generation 5: the explicit-LayerNorm forms travel too — plain weights fragment-major, LayerNorm gain / bias,
+    # packed with FWAMD_PACK_PLAIN / FWAMD_LN_UNFOLD: the explicit-LayerNorm forms travel too — plain weights fragment-major, LayerNorm gain / bias,
     # the tied embedding as a fragment-major projection (zero-padded like the folded one)
     for name in ("dec.0.self.qkv.w", "dec.1.cross.q.w", "dec.1.ffn1.w"):
         assert np.array_equal(t[name], frag_perm(_h(w[name]))), name
@@ -57,7 +63,7 @@ def test_int8_fragment_major_decoder_linears():
     cfg = get_config("micro")
     w = synthetic_weights(cfg, seed=6)
     h1, t1 = _parse_blob(pack_blob(cfg, w, _lib.COMPUTE_INT8_FLOAT16))
-    assert h1.reserved == 5
+    assert h1.reserved == 6
     o = OracleWhisper(cfg, w, int8=True)
     for name in ("dec.0.self.qkv", "dec.1.ffn2", "dec.0.cross.out"):
         wq = o.q[name + ".w"][0].numpy().astype(np.int8)

@@ -154,6 +154,42 @@ def test_encoder_attention(model, B, H, T, scale):
         assert err < 5e-3
 
 
+def test_encoder_attention_first_tile_far_below_zero(model):
+    """the softmax reference is fixed from the FIRST 64-key tile, whatever its sign: when every score of that tile lies
+    far below zero (here ~ -260 in the log2 domain, past the exp2 range of fp32) the reference must move down without
+    rescaling the (still empty) accumulators by exp2(+260) = inf (0 x inf = NaN would poison the query's output and
+    every later encoder layer)"""
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    B, H, T = 1, 2, 200
+    d = H * 64
+    q = _h(rng.standard_normal((B, T, d)).astype(np.float32))
+    k = _h(rng.standard_normal((B, T, d)).astype(np.float32))
+    v = _h(rng.standard_normal((B, T, d)).astype(np.float32))
+    # head 0: every query has a large component along e0, the first 64 keys point the other way: q.k / 8 = -180 (-260 in
+    # the log2 domain); head 1 the same with the LAST tile (the masked tail tile) far below instead
+    q[0, :, 0] = 12.0
+    k[0, :64, 0] = -120.0
+    q[0, :, 64] = 12.0
+    k[0, 192:, 64] = -120.0
+    out = np.empty_like(q)
+    _lib.check(lib.fw_test_attention(model._replicas[0].handle, _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), B, H, T,
+                                     _lib.ptr(out)))
+    qs = _h((q * (0.125 * 1.4426950408889634)).astype(np.float32)).reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    kh = k.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    vh = v.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    s2 = qs @ kh.transpose(0, 1, 3, 2)
+    s2 -= s2.max(-1, keepdims=True)
+    p2 = np.exp2(s2)
+    p2 /= p2.sum(-1, keepdims=True)
+    ref = (p2 @ vh).transpose(0, 2, 1, 3).reshape(B, T, d)
+    assert np.isfinite(out).all(), "NaN / inf from a first key tile far below zero"
+    err = np.abs(out - ref).max()
+    print(f"attention, first tile ~260 below zero (log2 domain): abs err {err:.2e}")
+    assert err < 3e-3
+
+
 # ---- decoder-step linears: the fragment-major register-streaming GEMM exactly as a decode step launches it ----
 def _dec_linear(model, x, W, bias=None, ln=None, res=None, act=0, int8=False):
     from faster_whisper_amd import _lib
