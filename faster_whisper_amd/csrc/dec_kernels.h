@@ -31,6 +31,10 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int cache_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag);
+// 0: the product's choice by launch size; 1: the first form (rounds 1-4); 2: latency form; 3: throughput form (same bits)
+void set_self_attn_form(int form);
+// changes whenever a measurement knob changed the kernels a decode step launches: cached step graphs carry it
+int kernel_forms_epoch();
 // slot_map: [B / kv_div] encoder chunk of the run -> chunk slot behind ck / cvt (the cross-attention pool)
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map);

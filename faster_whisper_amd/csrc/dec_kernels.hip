@@ -15,6 +15,11 @@
 #include <stdlib.h>
 #include <atomic>
 
+namespace fwd {
+static std::atomic<int> g_self_attn_form{0};   // fw_test_knob(2, ..): A/B of the self-attention forms
+static std::atomic<int> g_forms_epoch{0};      // bumped by every knob that changes which kernels a decode step launches
+}
+
 // ------------------------------------------------------------------------------------
 // K12: token + learned-position embedding  x[r] = E[tok[r]] + pos[p]
 // ------------------------------------------------------------------------------------
@@ -845,6 +850,178 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 }
 
 // ------------------------------------------------------------------------------------
+// K13, second form (round 5): the same arithmetic per row — same dot products, same DPP reductions, the same
+// ascending-position accumulation, every fused multiply-add written as one — with the memory rounds restructured.
+// What the first form above costs is DEPENDENT ROUND TRIPS, not bytes: per 32 positions one round of slot-table byte
+// loads, then one of K rows; in the PV phase every V row load was followed by its own vmcnt(0) (13 rounds at 104
+// positions): ~21 rounds x 0.4-0.5 us = the 10.5 us per layer of a solo step (profiles/r04_kernel_stats_w1.csv), and in
+// merged runs 67 % of the wave cycles waiting (profiles/r05_pmc_sq_w32.json).  Here:
+//   A  the row's slot table goes to LDS in ONE round of 4-byte loads (4 positions per lane and load);
+//   B  K rows in batches of 4 U per lane, addresses from LDS; PIPE: the next batch is issued before the current one is
+//      reduced;
+//   C  the first V batch is issued BEFORE the softmax reductions (its addresses do not depend on them);
+//   D  V rows in the same batches.
+// U = 4, no PIPE (latency form, solo runs): 128 positions per round — a 104-position step is one slot-table round, one K
+// round and one V round that overlaps the softmax.  U = 1, PIPE (throughput form, merged runs): 64 registers, 8 waves
+// per SIMD, two batches in flight.  Both return the same bits (the row's arithmetic does not depend on U), so a merged
+// run still returns what each caller gets alone.
+// ------------------------------------------------------------------------------------
+template <int U, bool PIPE, int MAXT>
+__global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
+                                                             half_t* __restrict__ vc, int n_ctx, int cache_ctx,
+                                                             int H, const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
+                                                             half_t* __restrict__ out, const int* __restrict__ d_step,
+                                                             int pos_fixed, int P, int R_total, int frag) {
+  extern __shared__ float sa_smem[];            // per wave: sp[n_ctx] floats, ssrc[n_ctx] ints
+  constexpr int NB = 4 * U;                     // rows per lane and batch; a batch covers 8 * NB positions
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sp = sa_smem + (size_t)wave * 2 * n_ctx;
+  int* ssrc = reinterpret_cast<int*>(sp + n_ctx);
+  const int h = blockIdx.x, c = blockIdx.y;
+  const int r = c * kmul + wave, kb = wave;
+  const int step = *d_step;
+  const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + step;
+  const int slot = c * Kbeam + kb;
+  const int cur = (pos_fixed >= 0) ? 0 : (step & 1);
+  const uint8_t* kvidx = kvidx2 + ((size_t)cur * R_total + slot) * n_ctx;
+  const half_t* qr = qkv + (size_t)r * 3 * d + h * 64;
+  const size_t head_stride = (size_t)cache_ctx * 64;
+  const size_t slot_stride = (size_t)H * head_stride;
+  const int pg = lane >> 3, cc = lane & 7;     // position group, 16-byte chunk of the 128-byte row
+  // ---- A: slot table -> LDS (n_ctx is a multiple of 4: launch_self_attn checks; the row starts 4-byte aligned) ----
+  for (int p4 = 4 * lane; p4 < pos; p4 += 256) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(kvidx + p4);
+    intx4 s4;
+    s4[0] = c * Kbeam + (int)(w & 0xffu); s4[1] = c * Kbeam + (int)((w >> 8) & 0xffu);
+    s4[2] = c * Kbeam + (int)((w >> 16) & 0xffu); s4[3] = c * Kbeam + (int)(w >> 24);
+    *reinterpret_cast<intx4*>(ssrc + p4) = s4;
+  }
+  const half8_t q8 = *reinterpret_cast<const half8_t*>(qr + cc * 8);
+  const half8_t kn8 = *reinterpret_cast<const half8_t*>(qr + d + cc * 8);
+  const half8_t vn8 = *reinterpret_cast<const half8_t*>(qr + 2 * d + cc * 8);
+  float q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] = (float)q8[e] * 0.125f;
+  if (pg == 0) {
+    *reinterpret_cast<half8_t*>(kc + slot * slot_stride + h * head_stride + (size_t)pos * 64 + cc * 8) = kn8;
+    *reinterpret_cast<half8_t*>(vc + slot * slot_stride + h * head_stride + (size_t)pos * 64 + cc * 8) = vn8;
+  }
+  auto dot8 = [&](const half8_t& k) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sacc = __builtin_fmaf(q[e], (float)k[e], sacc);
+    return sum8_dpp(sacc);                     // the 8 lanes of a position all hold its score
+  };
+  const float s_new = dot8(kn8);
+  float mx = s_new;
+  // sp / ssrc are private to the wave and a wave's LDS operations execute in order: no workgroup barrier, only a
+  // compiler-level one so that reads are not moved above the writes
+  __builtin_amdgcn_wave_barrier();
+  // wave-uniform base + 32-bit byte offset per lane (a layer's cache is < 4 GB: launch_self_attn checks): the loads
+  // take the scalar-base form, one address register per row in flight instead of two
+  const char* kbase = reinterpret_cast<const char*>(kc + h * head_stride);
+  const char* vbase = reinterpret_cast<const char*>(vc + h * head_stride);
+  const unsigned slot_bytes = (unsigned)(slot_stride * sizeof(half_t));
+  struct Batch { half8_t row[NB]; };
+  auto fetch = [&](Batch& b, const char* base, int p0) {   // rows of positions p0 + 8 j + pg (clamped into [0, pos))
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int p = p0 + 8 * j + pg;
+      const int pc = p < pos ? p : pos - 1;
+      const unsigned off = (unsigned)ssrc[pc] * slot_bytes + (unsigned)(pc * 128 + cc * 16);
+      b.row[j] = *reinterpret_cast<const half8_t*>(base + off);
+    }
+  };
+  auto score = [&](const Batch& b, int p0) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int p = p0 + 8 * j + pg;
+      const float sc = dot8(b.row[j]);
+      if (p < pos) {
+        if (cc == 0) sp[p] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    }
+  };
+  Batch b0, b1;
+  // ---- B: scores ----
+  if (pos > 0) {
+    fetch(b0, kbase, 0);
+    for (int p0 = 0; p0 < pos; p0 += 16 * NB) {
+      if (PIPE) {
+        // (unconditional prefetches — past the end they re-read the last position: a fetch under a branch makes the
+        //  wait-count pass assume the worst at the join and wait for the batch just issued)
+        fetch(b1, kbase, p0 + 8 * NB);
+        score(b0, p0);
+        fetch(b0, kbase, p0 + 16 * NB);
+        score(b1, p0 + 8 * NB);
+      } else {
+        score(b0, p0);
+        if (p0 + 8 * NB < pos) {
+          fetch(b0, kbase, p0 + 8 * NB);
+          score(b0, p0 + 8 * NB);
+          if (p0 + 16 * NB < pos) fetch(b0, kbase, p0 + 16 * NB);
+        }
+      }
+    }
+    // ---- C: the first V batch leaves before the reductions ----
+    fetch(b0, vbase, 0);
+  }
+  mx = wave_max_v(mx);
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.f;
+  for (int p = lane; p < pos; p += 64) {
+    const float e = __expf(sp[p] - mx);
+    sp[p] = e;
+    sum += e;
+  }
+  const float e_new = __expf(s_new - mx);
+  sum = wave_sum_v(sum) + e_new;
+  __builtin_amdgcn_wave_barrier();
+  // ---- D: P V, positions ascending per lane (p = pg, pg + 8, ...) ----
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  auto accum = [&](const Batch& b, int p0) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int p = p0 + 8 * j + pg;
+      if (p < pos) {
+        const float w = sp[p];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(w, (float)b.row[j][e], acc[e]);
+      }
+    }
+  };
+  for (int p0 = 0; p0 < pos; p0 += 16 * NB) {
+    if (PIPE) {
+      fetch(b1, vbase, p0 + 8 * NB);
+      accum(b0, p0);
+      fetch(b0, vbase, p0 + 16 * NB);
+      accum(b1, p0 + 8 * NB);
+    } else {
+      accum(b0, p0);
+      if (p0 + 8 * NB < pos) {
+        fetch(b0, vbase, p0 + 8 * NB);
+        accum(b0, p0 + 8 * NB);
+        if (p0 + 16 * NB < pos) fetch(b0, vbase, p0 + 16 * NB);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = sum_x8_x16_x32_v(acc[e]);   // the position groups: lanes 8, 16, 32 away
+  if (pg == 0) {
+    const float inv = 1.f / sum;
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((acc[e] + e_new * (float)vn8[e]) * inv);
+    half_t* dst = frag ? out + frag_off(r, h * 64 + cc * 8, d >> 5) : out + (size_t)r * d + h * 64 + cc * 8;
+    *reinterpret_cast<half8_t*>(dst) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // K14: decoder cross-attention.  One workgroup = (chunk, head); the kmul (<= 16) beam
 // queries of the chunk are the 16 columns of the MFMA tiles, so the chunk's K / V^T
 // (the dominant HBM stream of the whole decode: 2*1500*64*2 B per (chunk, head, layer))
@@ -1041,7 +1218,9 @@ static __device__ __forceinline__ float gumbel_noise(unsigned seed_lo, unsigned 
 // the suppress list is one bit per token (one scalar 8-byte load per 64 tokens of a wave), every element-wise rule
 // is a range test on uniform scalars.  Top-C: each thread keeps its own best (key, slot); a round is one wave
 // arg-max + 16 partials through LDS, and only the winning thread rescans its 56 values.
-template <bool SMP>
+// TXI: the first TXI values of every thread are text ids whatever the thread (ts_begin >= TXI * 1024: 48 for every
+// Whisper vocabulary, 0 for the synthetic test vocabularies) — a compile-time class split, no per-lane test there.
+template <bool SMP, int TXI>
 __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::GenDev gp, float* __restrict__ logits,
                                                                         const unsigned long long* __restrict__ sup_bits,
                                                                         const int* __restrict__ hist2,
@@ -1098,7 +1277,10 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
 #pragma unroll
   for (int i = 0; i < LP_NV; ++i) {
     const int v = tid + i * LP_THREADS;
-    val[i] = (v < V) ? lg[v] : NEG;
+    // (unconditional, clamped address: a load under `if (v < V)` becomes a branch around the load and the wait-count
+    //  pass then drains vmcnt(0) after every second one — 28 dependent round trips, 71 us per row, instead of one)
+    const float x = lg[v < V ? v : V - 1];
+    val[i] = (v < V) ? x : NEG;
   }
   // ---- timestamp-rule scalars (uniform): the position of the last timestamp token by a block arg-max ----
   int a_hi = 0;        // ids in [0, a_hi) are forbidden
@@ -1128,38 +1310,47 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   const int kill_a = (n < gp.min_new) ? gp.eot : -1;
   const int kill_b = gp.with_ts ? gp.no_ts : -1;
   // ---- element-wise masks, class maxima (text / timestamp ids) ----
+  // The 64 tokens a wave holds in val[i] are CONSECUTIVE ids (v0 = 64 * (16 i + wave) .. v0 + 63), so every rule — the
+  // suppress list, the id ranges of the timestamp rules, the single ids — is one 64-bit lane mask per i.  Lane l of
+  // the wave builds the mask of i = l (56 lanes, once); applying mask i is then two v_readlane + ONE v_cndmask (the
+  // mask as the select operand) per value instead of ~12 vector compares / selects per value.  The class split (text
+  // ids below ts_begin, timestamps from there) is uniform for every i but tb / 1024, where it is a per-lane test.
+  auto below = [](int nb) -> unsigned long long {   // lanes [0, nb) of a wave's 64 ids
+    return nb <= 0 ? 0ull : (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull));
+  };
+  auto span = [&](int lo, int hi, int v0) -> unsigned long long {   // ids in [lo, hi) among v0 .. v0 + 63
+    return below(hi - v0) & ~below(lo - v0);
+  };
+  unsigned km_lo, km_hi;
+  {
+    const int li = lane < LP_NV ? lane : LP_NV - 1;
+    const int v0 = (li * LP_WAVES + wv) * 64;
+    unsigned long long km = sup_bits[li * LP_WAVES + wv];
+    km |= below(a_hi - v0) | span(tb, b_hi, v0) | ~below(c_lo - v0) | span(kill_a, kill_a + 1, v0) |
+          span(kill_b, kill_b + 1, v0);
+    if (n == 0 && gp.suppress_blank) {   // first step only
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < gp.n_sup_begin) km |= span(gp.sup_begin[q], gp.sup_begin[q] + 1, v0);
+    }
+    km_lo = (unsigned)km; km_hi = (unsigned)(km >> 32);
+  }
   float mt = NEG, ms = NEG;
 #pragma unroll
   for (int i = 0; i < LP_NV; ++i) {
-    const int v = tid + i * LP_THREADS;
-    const unsigned long long bits = sup_bits[i * LP_WAVES + wv];   // wave-uniform: tokens 64 * (i * 16 + wv) ..
-    bool kill = (bits >> lane) & 1ull;
-    kill |= (v < a_hi) | ((v >= tb) & (v < b_hi)) | (v >= c_lo) | (v == kill_a) | (v == kill_b);
-    const float x = kill ? NEG : val[i];
+    const unsigned long long km = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)km_hi, i) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)km_lo, i);
+    const float x = __builtin_amdgcn_inverse_ballot_w64(km) ? NEG : val[i];
     val[i] = x;
-    if (v < tb) mt = fmaxf(mt, x); else ms = fmaxf(ms, x);
-  }
-  if (n == 0 && gp.suppress_blank && gp.n_sup_begin > 0) {   // first step only
-    mt = NEG; ms = NEG;
-    int sb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sb[q] = q < gp.n_sup_begin ? gp.sup_begin[q] : -1;
-#pragma unroll
-    for (int i = 0; i < LP_NV; ++i) {
-      const int v = tid + i * LP_THREADS;
-      bool kill = false;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) kill |= (v == sb[q]);
-      const float x = kill ? NEG : val[i];
-      val[i] = x;
-      if (v < tb) mt = fmaxf(mt, x); else ms = fmaxf(ms, x);
+    if (i < TXI) mt = fmaxf(mt, x);
+    else {
+      const bool text = tid + i * LP_THREADS < tb;
+      mt = fmaxf(mt, text ? x : NEG);
+      ms = fmaxf(ms, text ? NEG : x);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mt = fmaxf(mt, __shfl_xor(mt, o, 64));
-    ms = fmaxf(ms, __shfl_xor(ms, o, 64));
-  }
+  mt = wave_max_v(mt);
+  ms = wave_max_v(ms);
   if (lane == 0) { red_mt[wv] = mt; red_ms[wv] = ms; }
   __syncthreads();
   float max_t = red_mt[0], max_s = red_ms[0];
@@ -1170,16 +1361,16 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   float st = 0.f, ss = 0.f;
 #pragma unroll
   for (int i = 0; i < LP_NV; ++i) {
-    const int v = tid + i * LP_THREADS;
-    const bool text = v < tb;
-    const float e = __expf(val[i] - (text ? off_t : off_s));
-    if (text) st += e; else ss += e;
+    if (i < TXI) st += __expf(val[i] - off_t);
+    else {
+      const bool text = tid + i * LP_THREADS < tb;
+      const float e = __expf(val[i] - (text ? off_t : off_s));
+      st += text ? e : 0.f;     // (x + 0 == x: the bits of `if (text) st += e; else ss += e;`)
+      ss += text ? 0.f : e;
+    }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    st += __shfl_xor(st, o, 64);
-    ss += __shfl_xor(ss, o, 64);
-  }
+  st = wave_sum_v(st);   // the butterfly of __shfl_xor 32 .. 1 on the VALU: same partners, same bits (common.h)
+  ss = wave_sum_v(ss);
   if (lane == 0) { red_st[wv] = st; red_ss[wv] = ss; }
   __syncthreads();
   float sum_t = 0.f, sum_s = 0.f;
@@ -1195,8 +1386,10 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
     lse = hi + log1pf(expf(lo - hi));
   }
   // rule (e): if logsumexp(timestamps) > max(text) (in log-prob space the common lse cancels): text is masked
-  const bool mask_text = gp.with_ts && lse_s > max_t;
+  const bool mask_text = __builtin_amdgcn_readfirstlane((gp.with_ts && lse_s > max_t) ? 1 : 0) != 0;   // uniform
   if (mask_text) lse = lse_s;
+  // (-inf - finite = -inf: the masked ids need no test; lse is -inf only when every id is masked)
+  const float lse_sub = (lse == NEG) ? 0.f : lse;
   // ---- log-probs; this thread's best key ----
   const float cum = cum2[(size_t)cur * gp.R + r];
   constexpr bool smp = SMP;   // a separate instantiation: 2 x 56 inlined logf stay out of the beam / greedy kernel
@@ -1207,8 +1400,8 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   for (int i = 0; i < LP_NV; ++i) {
     const int v = tid + i * LP_THREADS;
     float x = val[i];
-    if (mask_text && v < tb) x = NEG;
-    x = (x == NEG) ? NEG : x - lse;
+    if (mask_text) x = (v < tb) ? NEG : x;
+    x = x - lse_sub;
     val[i] = x;
     float key = x;
     if (smp && x != NEG) key = x * gp.inv_temp + gumbel_noise(gp.seed_lo, gp.seed_hi, (unsigned)r, (unsigned)step, (unsigned)v);
@@ -1219,23 +1412,18 @@ __global__ __launch_bounds__(LP_THREADS) void dec_logits_process_kernel(fwd::Gen
   for (int cidx = 0; cidx < C; ++cidx) {
     float k = bkey;
     int t = (bq < 0) ? NONE : tid + bq * LP_THREADS;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ok = __shfl_xor(k, o, 64);
-      const int ot = __shfl_xor(t, o, 64);
-      if (ok > k || (ok == k && ot < t)) { k = ok; t = ot; }
-    }
+    wave_argmax_v(k, t);        // DPP / permlane exchanges (the ds_bpermute butterfly was ~1 500 cycles per round)
     const int par = cidx & 1;   // partials double-buffered: one barrier per round
     if (lane == 0) { bkey_s[par][wv] = k; btok_s[par][wv] = t; }
     __syncthreads();
-    float wk = bkey_s[par][0];
-    int wt = btok_s[par][0];
-#pragma unroll
-    for (int i = 1; i < LP_WAVES; ++i) {
-      const float ok = bkey_s[par][i];
-      const int ot = btok_s[par][i];
-      if (ok > wk || (ok == wk && ot < wt)) { wk = ok; wt = ot; }
-    }
+    // the 16 wave partials: lane l takes partial l % 16, four exchanges inside the 16-lane row leave the winner in
+    // every lane (the relation is a total order on (key, token): the result does not depend on the exchange pattern)
+    float wk = bkey_s[par][lane & (LP_WAVES - 1)];
+    int wt = btok_s[par][lane & (LP_WAVES - 1)];
+    argmax_pair_step(wk, wt, dpp_f<FW_DPP_XOR1>(wk), dpp_i<FW_DPP_XOR1>(wt));
+    argmax_pair_step(wk, wt, dpp_f<FW_DPP_XOR2>(wk), dpp_i<FW_DPP_XOR2>(wt));
+    argmax_pair_step(wk, wt, dpp_f<FW_DPP_ROR4>(wk), dpp_i<FW_DPP_ROR4>(wt));
+    argmax_pair_step(wk, wt, dpp_f<FW_DPP_ROR8>(wk), dpp_i<FW_DPP_ROR8>(wt));
     if (wt == NONE) {   // nothing left on this row
       if (tid == 0) {
         cand_val[(size_t)r * 32 + cidx] = NEG;
@@ -1680,9 +1868,21 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
                       int pos_fixed, int P, int R_total, int frag) {
   // one workgroup per (head, chunk), one wave per row of the chunk (kmul <= 16); LDS: scores + source slots per wave
-  dec_self_attn_kernel<<<dim3(H, rows / kmul), kmul * 64, (size_t)kmul * 2 * n_ctx * sizeof(float), st>>>(
-      qkv, d, kc, vc, n_ctx, cache_ctx, H, kvidx2, Kbeam, kmul, out, d_step, pos_fixed, P, R_total, frag);
+  const dim3 grid(H, rows / kmul);
+  const size_t lds = (size_t)kmul * 2 * n_ctx * sizeof(float);
+  int form = g_self_attn_form.load(std::memory_order_relaxed);   // 0: by size (product); 1: first form; 2 / 3: forced
+  // the second form needs n_ctx % 4 == 0 (4-byte slot-table loads) and a layer's cache below 4 GB (32-bit offsets)
+  if ((n_ctx & 3) != 0 || (size_t)R_total * cache_ctx * d * sizeof(half_t) >= ((size_t)1 << 32)) form = 1;
+  if (form == 0) form = (kmul <= 8 && (int)(grid.x * grid.y) <= 768) ? 2 : 3;
+  if (form == 2 && kmul > 8) form = 3;
+#define SA_ARGS qkv, d, kc, vc, n_ctx, cache_ctx, H, kvidx2, Kbeam, kmul, out, d_step, pos_fixed, P, R_total, frag
+  if (form == 1) dec_self_attn_kernel<<<grid, kmul * 64, lds, st>>>(SA_ARGS);
+  else if (form == 2) dec_self_attn2_kernel<4, false, 512><<<grid, kmul * 64, lds, st>>>(SA_ARGS);   // latency form
+  else dec_self_attn2_kernel<1, true, 1024><<<grid, kmul * 64, lds, st>>>(SA_ARGS);                  // throughput form
+#undef SA_ARGS
 }
+void set_self_attn_form(int form) { g_self_attn_form.store(form); g_forms_epoch.fetch_add(1); }
+int kernel_forms_epoch() { return g_forms_epoch.load(); }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map) {
@@ -1699,12 +1899,14 @@ void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, in
 void launch_logits_process(hipStream_t st, const GenDev& gp, float* logits, const unsigned long long* sup_bits,
                            const int* hist2, const float* cum2, const int* d_step, const int* done, float* cand_val,
                            int* cand_tok) {
-  if (gp.sample)
-    dec_logits_process_kernel<true><<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_bits, hist2, cum2, d_step, done,
-                                                                 cand_val, cand_tok);
-  else
-    dec_logits_process_kernel<false><<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_bits, hist2, cum2, d_step, done,
-                                                                  cand_val, cand_tok);
+  // every Whisper vocabulary keeps its timestamp ids above 48 * 1024 (ts_begin 50 363 .. 50 365); the synthetic
+  // test vocabularies do not: they take the instantiation with a per-lane class test everywhere
+  const bool wide = gp.ts_begin >= 48 * LP_THREADS;
+#define LP_GO(SMP, TXI) \
+  dec_logits_process_kernel<SMP, TXI><<<gp.R, LP_THREADS, 0, st>>>(gp, logits, sup_bits, hist2, cum2, d_step, done, cand_val, cand_tok)
+  if (gp.sample) { if (wide) LP_GO(true, 48); else LP_GO(true, 0); }
+  else { if (wide) LP_GO(false, 48); else LP_GO(false, 0); }
+#undef LP_GO
 }
 
 void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val, const int* cand_tok, int* hist2,

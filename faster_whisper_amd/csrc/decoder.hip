@@ -59,6 +59,8 @@ struct GraphSlot {
   hipGraphExec_t exec = nullptr;
   GenDev key;
   uint64_t stamp = 0;
+  int forms = 0;    // fwd::kernel_forms_epoch() at capture: a measurement knob that changes which kernels a step
+                    // launches (fw_test_knob) must not be answered with a graph captured before it was set
 };
 
 struct GenWorkspace {
@@ -709,7 +711,9 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
     hipGraphExec_t exec = nullptr;
     if (g->graphs_enabled && !m->prof_on) {
       for (GraphSlot& gs : g->graphs)
-        if (gs.exec && memcmp(&gs.key, &gp, sizeof(gp)) == 0) { exec = gs.exec; gs.stamp = ++g->graph_clock; }
+        if (gs.exec && gs.forms == fwd::kernel_forms_epoch() && memcmp(&gs.key, &gp, sizeof(gp)) == 0) {
+          exec = gs.exec; gs.stamp = ++g->graph_clock;
+        }
       if (!exec) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -724,7 +728,7 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
               for (GraphSlot& gs : g->graphs) if (gs.stamp < slot->stamp) slot = &gs;
               if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
             }
-            slot->exec = ne; slot->key = gp; slot->stamp = ++g->graph_clock;
+            slot->exec = ne; slot->key = gp; slot->stamp = ++g->graph_clock; slot->forms = fwd::kernel_forms_epoch();
             exec = ne;
           }
           if (graph) (void)hipGraphDestroy(graph);

@@ -1839,8 +1839,9 @@ int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {
-  FW_CHECK_ARG(id == 1, "unknown knob %d", id);
-  fwk::g_gemm_order.store(value);
+  FW_CHECK_ARG(id == 1 || id == 2, "unknown knob %d", id);
+  if (id == 1) fwk::g_gemm_order.store(value);
+  else fwd::set_self_attn_form(value);
   return FW_OK;
 }
 

@@ -371,3 +371,34 @@ def test_generate_greedy_literal_ids_peaked(name):
                 assert m.min() > 2 * MARGIN
                 assert g.sequences_ids[0] == r.sequences_ids[0], (b, g.sequences_ids[0], r.sequences_ids[0])
                 assert abs(g.scores[0] - r.scores[0]) < 1e-3 * max(1.0, abs(r.scores[0]))
+
+
+def test_self_attention_forms_return_the_same_bits(setup):
+    """Round 5: the decoder self-attention has a latency form (solo runs) and a throughput form (merged runs) next to the
+    first form of rounds 1-4 (dec_kernels.hip: dec_self_attn2_kernel).  All of them keep the row's arithmetic — same dot
+    products, same reductions, the same ascending-position accumulation — so which one a launch takes must not change a
+    bit of any result: beam search (ids, scores, no-speech) over 40 steps (the slot table is exercised by the beam
+    reorders, 40 + prompt positions span two 32-position batches of the throughput form) and greedy with timestamps."""
+    from faster_whisper_amd import _lib
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    lib = _lib.load()
+    enc = model.encode(StorageView.from_array(feats))
+    res = {}
+    try:
+        for form in (1, 2, 3, 0):
+            _lib.check(lib.fw_test_knob(2, form))
+            out = []
+            for beam, ts in ((5, False), (1, True), (3, True)):
+                prompt = _prompt(cfg, ts)
+                kw = dict(beam_size=beam, max_length=len(prompt) + 40, suppress_blank=True, suppress_tokens=_suppress(cfg),
+                          max_initial_timestamp_index=50, num_hypotheses=min(beam, 2))
+                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+                out.append([(g.sequences_ids, [np.float32(s).tobytes() for s in g.scores],
+                             np.float32(g.no_speech_prob).tobytes()) for g in got])
+            res[form] = out
+    finally:
+        _lib.check(lib.fw_test_knob(2, 0))
+    for form in (2, 3, 0):
+        assert res[form] == res[1], f"self-attention form {form} differs from the first form"
+    print(f"[{cfg.name}] self-attention forms 1 / 2 / 3 / auto: identical ids, scores and no-speech bits over 3 configurations")
