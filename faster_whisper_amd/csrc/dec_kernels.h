@@ -35,6 +35,7 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 void set_self_attn_form(int form);
 // changes whenever a measurement knob changed the kernels a decode step launches: cached step graphs carry it
 int kernel_forms_epoch();
+void bump_kernel_forms_epoch();
 // slot_map: [B / kv_div] encoder chunk of the run -> chunk slot behind ck / cvt (the cross-attention pool)
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map);
@@ -56,6 +57,8 @@ int launch_dec_gemm_skinny_tiles(hipStream_t st, int tiles, const half_t* xf, co
 int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                         int N, int K, int act);
+// shadow-branch touch of the weight tiles launch_dec_gemm_skinny(R, N, K) will read (dec_kernels.hip); sink: any int in HBM
+int launch_dec_wprefetch(hipStream_t st, const half_t* Wf, int R, int N, int K, int* sink);
 int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
                                  const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
                                  int K);

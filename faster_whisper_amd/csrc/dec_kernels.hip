@@ -1749,6 +1749,39 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
   return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// Weight prefetch for SOLO decode runs (opt-in: FWAMD_WPREFETCH=1, measured as an A/B in profiles/).  A solo step is a
+// chain of 261 dependent launches whose linears each start with a cold HBM round trip for weights nobody asked for yet
+// (a d x d linear streams 3.3 MB in 4.4-5 us = 0.7 TB/s).  The weights do not depend on anything: a shadow branch of the
+// step graph touches the NEXT linear's weight tiles while the current kernel runs, so that they sit in L2 when their
+// consumer starts.  L2 is per XCD and the hardware places workgroup b on XCD b % 8: block j here reads exactly the
+// bytes the consumer's workgroups (j, *) will read (grid.x of the register-streaming kernel, a multiple of 8 wide), so
+// every tile lands in the L2 of the XCD that will use it.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_wprefetch_kernel(const char* __restrict__ W, unsigned bytes_per_block,
+                                                           int* __restrict__ sink) {
+  const char* p = W + (size_t)blockIdx.x * bytes_per_block;
+  intx4 acc = {0, 0, 0, 0};
+#pragma unroll 8
+  for (unsigned off = threadIdx.x * 16u; off < bytes_per_block; off += 256u * 16u) {
+    const intx4 v = *reinterpret_cast<const intx4*>(p + off);
+    acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+  }
+  // never true for real weights and never taken twice; keeps the loads alive
+  if (sink && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x5a17c3e1 && acc[0] == 0x1badb002) *sink = acc[1];
+}
+
+static bool skinny_one_tile(int R, int N) { return R <= 16 || (R <= 96 && N <= 1280); }
+
+// touches the weight tiles of the [N][K] linear a run of R rows will launch next (register-streaming kernel only)
+int launch_dec_wprefetch(hipStream_t st, const half_t* Wf, int R, int N, int K, int* sink) {
+  if (R >= DEC_BIG_MIN_ROWS || K % 32 != 0 || N % 32 != 0) return -1;
+  const int nt = skinny_one_tile(R, N) ? 1 : 2;
+  const unsigned bytes = (unsigned)nt * (unsigned)(K >> 5) * 1024u;   // a column tile = K/32 fragments of 1 KB
+  dec_wprefetch_kernel<<<N / 16 / nt, 256, 0, st>>>(reinterpret_cast<const char*>(Wf), bytes, sink);
+  return 0;
+}
+
 // The per-layer decoder linears: K split over the waves of a workgroup, 2 x 2 tiles of 16 x 16 per workgroup
 // (measured best of {1,2} x {1,2}: profiles/r01_sweep_dec_gemm_frag_tiles.jsonl), row groups on grid.y so any
 // number of rows works (a merged decode run carries up to 128 chunks x 5 beams).  out (row-major) and out_frag
@@ -1777,7 +1810,7 @@ int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, c
   // in flight at once: single utterance (5 rows) 41.8 -> 31.4 us per layer, and at a solo batch (80 rows) for the
   // linears with 1280 columns (5.6 -> 4.4, 12.1 -> 10.0 us); 2 x 2 tiles otherwise, also for merged runs below
   // DEC_BIG_MIN_ROWS (4 x 2, 2 x 4, 4 x 4 tiles measured no better there: profiles/r03_dec_linear_bench.txt, README.md)
-  const bool one_tile = R <= 16 || (R <= 96 && N <= 1280);
+  const bool one_tile = skinny_one_tile(R, N);
   if (one_tile) {
     if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
@@ -1883,6 +1916,7 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
 }
 void set_self_attn_form(int form) { g_self_attn_form.store(form); g_forms_epoch.fetch_add(1); }
 int kernel_forms_epoch() { return g_forms_epoch.load(); }
+void bump_kernel_forms_epoch() { g_forms_epoch.fetch_add(1); }
 
 void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck, const half_t* cvt, int T, int kvp,
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map) {

@@ -241,6 +241,11 @@ static int gen_workspace_build(Model* m) {
   FW_CHECK_ARG(R <= 2048, "decode_batch * max_beam must be <= 2048 (got %zu)", R);
   FW_HIP(hipSetDevice(m->device));
   if (!m->dec_stream) FW_HIP(hipStreamCreateWithFlags(&m->dec_stream, hipStreamNonBlocking));
+  if (!m->pf_stream) {
+    FW_HIP(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
+    FW_HIP(hipEventCreateWithFlags(&m->pf_fork, hipEventDisableTiming));
+    FW_HIP(hipEventCreateWithFlags(&m->pf_join, hipEventDisableTiming));
+  }
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
   A(g->slot_map, R);
@@ -385,6 +390,19 @@ struct StepCfg {
     }                                                                   \
   } while (0)
 
+// weight prefetch of solo runs: FWAMD_WPREFETCH=1, or fw_test_knob(3, 0 / 1) for an A/B inside one process
+static std::atomic<int> g_wprefetch{-1};
+static bool wprefetch_on() {
+  int v = g_wprefetch.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("FWAMD_WPREFETCH");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+    g_wprefetch.store(v);
+  }
+  return v != 0;
+}
+void set_wprefetch(int on) { g_wprefetch.store(on ? 1 : 0); fwd::bump_kernel_forms_epoch(); }
+
 // One decoder forward over `rows` rows.  Everything that varies from step to step lives in HBM (d_step, beam
 // tables), and everything a captured graph bakes in by value is part of GenDev (the graph key).
 static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
@@ -415,6 +433,25 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
                                      L.K, act);
   };
   const int frag = i8 ? 0 : 1;
+  // ---- weight prefetch one linear ahead on a shadow branch of the step graph (opt-in, solo-size fp16 runs, only while
+  //      the step is being CAPTURED: the eager steps of a run are few).  pf(L) is called right before the launch of the
+  //      kernel that precedes linear L's predecessor... concretely: before kernel k, with L = the first linear after k;
+  //      the branch forks from the completion of kernel k - 1, so the prefetch runs BESIDE kernel k and the main chain
+  //      never waits for it (the branch is joined once, at the end of the step: a capture must end with one stream).
+  bool pf_on = false;
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (wprefetch_on() && !i8 && rows <= 160 && m->pf_stream && hipStreamIsCapturing(st, &cs) == hipSuccess)
+      pf_on = cs == hipStreamCaptureStatusActive;
+  }
+  bool pf_used = false;
+  auto pf = [&](const LinearW& L) {
+    if (!pf_on) return;
+    if (hipEventRecord(m->pf_fork, st) != hipSuccess) return;
+    if (hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0) != hipSuccess) return;
+    fwd::launch_dec_wprefetch(m->pf_stream, L.w, rows, L.N, L.K, nullptr);
+    pf_used = true;
+  };
   // fp16, explicit-LayerNorm order (Model::ln_unfold == 2): the LayerNorm is its own kernel, its fp16 output (fragment-
   // major) feeds the plain weight — the rounding points of an fp16 LayerNorm followed by an fp16 GEMM
   const bool unf = !i8 && m->ln_unfold >= 2;
@@ -430,12 +467,14 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     half_t* vc = g->sv + (size_t)l * gp.cache_rows * gp.ctx * d;
     const half_t* ck = pool->ck + (size_t)l * pool->n_slots() * d * kvp;
     const half_t* cvt = pool->cvt + (size_t)l * pool->n_slots() * d * kvp;
+    pf(L.out);
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
       else if (unf) DG(lin_u(L.ln1, L.qkv_p, g->qkv, nullptr, 0));
       else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
     }
+    pf(L.cq);
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0, st);
       fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, gp.ctx, H, g->kvidx2, gp.K, s.kmul, frag ? g->att_frag : g->att, rows,
@@ -458,22 +497,26 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
       fwd::launch_cross_probs(st, g->qc, d, ck + (size_t)s.kv_slot0 * d * kvp, T, kvp, s.sel_heads_dev + off, n, s.n_sel_total,
                               s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
     }
+    pf(L.cout);
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * (s.B / gp.kv_div) * (double)T * d, st);
       fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, kvp, s.kmul, frag ? g->att_frag : g->att, s.B, H, s.done,
                              gp.kv_div, frag, g->slot_map);
     }
+    pf(L.ffn1);
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d, st);
       if (i8) DG(lin_q(g->att, nullptr, L.cout, g->x, g->x, 0));
       else DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0));
     }
+    pf(L.ffn2);
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
       else if (unf) DG(lin_u(L.ln3, L.ffn1_p, nullptr, g->ffn_frag, 1));
       else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
     }
+    if (l + 1 < c.n_dec_layers) pf(m->dec[l + 1].qkv);
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
@@ -499,6 +542,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
     fwd::launch_nospeech(st, g->logits, c.n_vocab, s.nospeech_rowmul, c.tok_no_speech, g->no_speech, s.B);
   }
+  if (s.beam_tail) pf(m->dec[0].qkv);   // the next step's first linear, beside the logits rules
   if (s.beam_tail) {
     ProfScope ps(m, PF_DEC_SAMPLE, 0, 8.0 * rows * c.n_vocab, st);
     fwd::launch_logits_process(st, gp, g->logits, g->sup_bits, g->hist2, g->cum2, g->d_step, g->done, g->cand_val,
@@ -506,6 +550,10 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     fwd::launch_beam_update(st, gp, g->cand_val, g->cand_tok, g->hist2, g->cum2, g->kvidx2, g->cur_tok, g->d_step,
                             g->done, g->n_done, g->n_fin, g->fin_tok, g->fin_len, g->fin_score, g->fin_cum);
     fwd::launch_step_advance(st, g->d_step);
+  }
+  if (pf_used) {   // the shadow branch rejoins: a capture ends with every forked stream joined
+    FW_HIP(hipEventRecord(m->pf_join, m->pf_stream));
+    FW_HIP(hipStreamWaitEvent(st, m->pf_join, 0));
   }
   return FW_OK;
 }

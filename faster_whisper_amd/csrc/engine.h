@@ -200,6 +200,9 @@ struct Model {
   void* self = nullptr;         // the fw_model this Model lives in
   Model* blob_owner = nullptr;  // the model whose blob this one borrows (fw_model_create_from_blob_dev on fw_model_blob)
   hipStream_t dec_stream = nullptr;
+  // shadow branch of the solo step graph (FWAMD_WPREFETCH=1): weight prefetch one linear ahead (decoder.hip: run_step)
+  hipStream_t pf_stream = nullptr;
+  hipEvent_t pf_fork = nullptr, pf_join = nullptr;
   std::mutex dec_mu;
   DecodeGroup grp;
 
@@ -244,6 +247,7 @@ int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, ha
 int run_encoder(Model* m, int B, half_t* out);
 
 // decoder entry points (decoder.hip)
+void set_wprefetch(int on);                   // fw_test_knob(3, ..): the weight-prefetch branch of solo step graphs
 uint64_t next_tensor_id();
 int gen_workspace_ensure(Model* dm);          // creates dm's decode workspace on first use (caller holds dm->dec_mu)
 void gen_workspace_free(Model* m);

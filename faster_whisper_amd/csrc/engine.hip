@@ -1105,6 +1105,9 @@ void fw_model_free(fw_model* fm) {
   gen_workspace_free(m);
   cross_pool_free(m);       // (a lane has none of its own: it reads the primary's)
   if (m->dec_stream) (void)hipStreamDestroy(m->dec_stream);
+  if (m->pf_stream) (void)hipStreamDestroy(m->pf_stream);
+  if (m->pf_fork) (void)hipEventDestroy(m->pf_fork);
+  if (m->pf_join) (void)hipEventDestroy(m->pf_join);
   for (half_t* p : m->enc_pool) (void)hipFree(p);
   m->enc_pool.clear();
   void* ptrs[] = {m->lm_consts, m->lm_filtT, m->ws_pcm, m->ws_offsets, m->ws_raw, m->ws_chunk_max, m->ws_nframes,
@@ -1839,9 +1842,10 @@ int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {
-  FW_CHECK_ARG(id == 1 || id == 2, "unknown knob %d", id);
+  FW_CHECK_ARG(id >= 1 && id <= 3, "unknown knob %d", id);
   if (id == 1) fwk::g_gemm_order.store(value);
-  else fwd::set_self_attn_form(value);
+  else if (id == 2) fwd::set_self_attn_form(value);
+  else set_wprefetch(value);
   return FW_OK;
 }
 

@@ -59,7 +59,8 @@ int32_t fw_bench_attention(fw_model* m, int32_t B, int32_t H, int32_t T, int32_t
 int32_t fw_dec_big_min_rows(void);
 /* process-wide measurement knob for A/B runs inside one process.  id 1: encoder GEMM tile order (1 = blocked, the
  * product's; 0 = n fastest across the whole width, rounds 1-3).  id 2: decoder self-attention form (0 = by launch size,
- * the product's; 1 = the first form of rounds 1-4; 2 = latency form; 3 = throughput form — all four return the same bits) */
+ * the product's; 1 = the first form of rounds 1-4; 2 = latency form; 3 = throughput form — all four return the same bits).  id 3: weight prefetch one linear ahead on a shadow
+ * branch of the solo decode step graph (0 / 1; FWAMD_WPREFETCH sets the default) */
 int32_t fw_test_knob(int32_t id, int32_t value);
 
 #ifdef __cplusplus

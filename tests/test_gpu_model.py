@@ -402,3 +402,28 @@ def test_self_attention_forms_return_the_same_bits(setup):
     for form in (2, 3, 0):
         assert res[form] == res[1], f"self-attention form {form} differs from the first form"
     print(f"[{cfg.name}] self-attention forms 1 / 2 / 3 / auto: identical ids, scores and no-speech bits over 3 configurations")
+
+
+def test_weight_prefetch_branch_same_results(setup):
+    """Round 5, opt-in (FWAMD_WPREFETCH=1 / fw_test_knob 3): the captured step graph of a solo run gets a shadow branch
+    that touches the next linear's weight tiles beside the current kernel.  It computes nothing: results must not move,
+    and the two-stream capture (fork per linear, one join per step) must instantiate and replay."""
+    from faster_whisper_amd import _lib
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    lib = _lib.load()
+    enc = model.encode(StorageView.from_array(feats))
+    prompt = _prompt(cfg, True)
+    kw = dict(beam_size=5, max_length=len(prompt) + 30, suppress_blank=True, suppress_tokens=_suppress(cfg),
+              max_initial_timestamp_index=50)
+    res = {}
+    try:
+        for on in (0, 1, 0):
+            _lib.check(lib.fw_test_knob(3, on))
+            got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+            got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)   # the replay
+            res.setdefault(on, []).append([(g.sequences_ids, g.scores, g.no_speech_prob) for g in got])
+    finally:
+        _lib.check(lib.fw_test_knob(3, 0))
+    assert res[1][0] == res[0][0] == res[0][1]
+    print(f"[{cfg.name}] weight-prefetch branch on / off: identical results")
