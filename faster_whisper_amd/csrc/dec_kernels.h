@@ -24,13 +24,17 @@ struct GenDev {
   int ctx, cache_rows;     // self-attention cache geometry of this run: positions per slot, slots per layer
 };
 
+// blk_n > 0: POSITION BLOCKS (prompt forward, align) — the rows of a chunk are blk_n consecutive positions pos_fixed ..
+// of its beam slot 0 (row = chunk * blk_n + j) instead of beams at one position; same per-row arithmetic, same bits
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d,
-                  const int* d_step, int pos_fixed, int P);
+                  const int* d_step, int pos_fixed, int P, int blk_n = 0);
+// whether launch_self_attn can take position blocks for this cache geometry
+bool self_attn_block_ok(int n_ctx, int cache_ctx, int d, int R_total);
 // n_ctx: stride of the slot table (the text context); cache_ctx: positions per slot of the K/V cache of this run
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int cache_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
-                      int pos_fixed, int P, int R_total, int frag);
+                      int pos_fixed, int P, int R_total, int frag, int blk_n = 0);
 // 0: the product's choice by launch size; 1: the first form (rounds 1-4); 2: latency form; 3: throughput form (same bits)
 void set_self_attn_form(int form);
 // changes whenever a measurement knob changed the kernels a decode step launches: cached step graphs carry it
@@ -42,13 +46,16 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
 // rows from which launch_dec_gemm_frag hands a decode run's linears to the GEMM-shaped kernel
 int dec_big_min_rows();
 // frag = 1: `out` is a fragment-major [rows/16][d/32][64][8] buffer (input of launch_dec_gemm_frag)
+// next (optional): the linear the run launches after this one — a solo-size launch touches its weights into L2 with
+// one extra wave per workgroup (dec_kernels.hip: PF); results do not depend on it
+struct NextLinear { const half_t* w; int N, K; int* sink; };
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                         int N, int K, int act);
+                         int N, int K, int act, const NextLinear* next = nullptr);
 // the skinny kernel whatever the row count (launch_dec_gemm_frag hands merged runs to the GEMM-shaped kernel)
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                           int N, int K, int act);
+                           int N, int K, int act, const NextLinear* next = nullptr);
 // ... with an explicit tile grouping (1: one 16 x 16 tile per workgroup, 2: 2 x 2 tiles)
 int launch_dec_gemm_skinny_tiles(hipStream_t st, int tiles, const half_t* xf, const half_t* Wf, const half_t* bias,
                                  const float* s1, const float* cf, const half_t* res, int ldr, half_t* out, int ldo,
@@ -57,8 +64,6 @@ int launch_dec_gemm_skinny_tiles(hipStream_t st, int tiles, const half_t* xf, co
 int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                         const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
                         int N, int K, int act);
-// shadow-branch touch of the weight tiles launch_dec_gemm_skinny(R, N, K) will read (dec_kernels.hip); sink: any int in HBM
-int launch_dec_wprefetch(hipStream_t st, const half_t* Wf, int R, int N, int K, int* sink);
 int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
                                  const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
                                  int K);
@@ -78,9 +83,10 @@ void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val,
                         float* cum2, uint8_t* kvidx2, int* cur_tok, const int* d_step, int* done, int* n_done,
                         int* n_fin, int* fin_tok, int* fin_len, float* fin_score, float* fin_cum);
 void launch_step_advance(hipStream_t st, int* d_step);
+// row b reads logits row b * row_mul
 void launch_token_prob(hipStream_t st, const float* logits, int V, const int* target, float* out, int out_stride,
-                       int out_off, int rows);
+                       int out_off, int rows, int row_mul = 1);
 void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, int kvp, const int* heads,
-                        int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B);
+                        int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B, int blk_n = 0);
 
 }  // namespace fwd

@@ -31,12 +31,13 @@ __device__ __forceinline__ size_t frag_off(int row, int k, int KS) {
   return ((size_t)((row >> 4) * KS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (row & 15)) * 8 + (k & 7);
 }
 
+// blk_n > 0 (position blocks: prompt forward, align): row r = chunk * blk_n + j is position pos_fixed + j
 __global__ void dec_embed_kernel(const int* __restrict__ tok, const half_t* __restrict__ emb,
                                  const half_t* __restrict__ pos_emb, half_t* __restrict__ x,
                                  half_t* __restrict__ xfrag, int d, const int* __restrict__ d_step, int pos_fixed,
-                                 int P) {
+                                 int P, int blk_n) {
   const int r = blockIdx.x;
-  const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + *d_step;
+  const int pos = blk_n > 0 ? pos_fixed + r % blk_n : (pos_fixed >= 0 ? pos_fixed : P - 1 + *d_step);
   const half2_t* e = reinterpret_cast<const half2_t*>(emb + (size_t)tok[r] * d);
   const half2_t* pe = reinterpret_cast<const half2_t*>(pos_emb + (size_t)pos * d);
   half2_t* xo = reinterpret_cast<half2_t*>(x + (size_t)r * d);
@@ -141,11 +142,24 @@ static __device__ __forceinline__ half4_t dec_epilogue4_i8(const int (&v)[4], fl
 //     runs (320-1 680 rows) that L2 traffic, not HBM, is what bounds the kernel (profiles/NOTES.md);
 //   * fixed-order reduction of the WAVES partial tiles through LDS, epilogue spread over the waves.
 // ------------------------------------------------------------------------------------
-template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0>
-__global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
+//   * PF (solo-size runs, round 5): one EXTRA wave per workgroup that computes nothing — it touches this workgroup's share of
+//     the NEXT linear's weights (PfArgs) and leaves.  A solo step is a chain of 261 dependent launches whose linears each
+//     start with a cold HBM round trip for weights that depend on nothing; touched one launch ahead they sit in L2 when
+//     their consumer starts.  L2 is per XCD and the hardware places workgroup w on XCD w % 8: the consumer's column group j
+//     runs on XCD j % 8 (its grid.x is a multiple of 8), so it is touched by workgroups of this launch with w % 8 == j % 8, in
+//     units of 4 KB dealt round-robin.  The wave has its own vmcnt, so the other waves never wait for its loads; it takes
+//     no barrier (a wave that has ended is not counted).
+struct PfArgs {
+  const char* base;     // next linear's fragment-major weights; null: nothing to touch
+  unsigned cg_bytes;    // bytes of one column group of the consumer (NT' column tiles x K'/32 fragments of 1 KB)
+  int groups;           // column groups of the consumer (its grid.x)
+  int* sink;            // an int in HBM nobody reads (keeps the loads alive)
+};
+template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0, bool PF = false>
+__global__ __launch_bounds__((WAVES + (PF ? 1 : 0)) * 64) void dec_gemm_frag_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
-    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
+    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act, PfArgs pf) {
   // RT x NT tiles of 16 x 16 per workgroup (larger tiles re-use the x / W fragments in registers and cut the L2
   // re-reads at the price of fewer, fatter workgroups: launch_dec_gemm_frag_variant / profiles/dec_linear_bench.py)
   __shared__ float red[WAVES][RT * NT][64][4];
@@ -153,6 +167,27 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
   constexpr int CH = CH_ ? CH_ : 20 / (RT + NT);   // k-steps in flight per wave: (RT + NT) * CH * 16 B per lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (PF && wave == WAVES) {   // the prefetch wave
+    if (pf.base) {
+      const int w = blockIdx.x + gridDim.x * blockIdx.y;      // this workgroup runs on XCD w % 8
+      const int xcd = w & 7, t = w >> 3, T = (gridDim.x * gridDim.y + 7 - xcd) >> 3;   // T: workgroups on that XCD
+      const int S = pf.cg_bytes >> 12;                        // 4 KB units per column group
+      const int units = ((pf.groups - xcd + 7) >> 3) * S;     // ... of the groups j = xcd, xcd + 8, ...
+      const int mine = units > t ? (units - t + T - 1) / T : 0;
+      intx4 acc = {0, 0, 0, 0};
+#pragma unroll 16
+      for (int q = 0; q < mine * 4; ++q) {
+        const int u = t + (q >> 2) * T;
+        const int j = xcd + 8 * (u / S), sub = u - (u / S) * S;
+        const intx4 v = *reinterpret_cast<const intx4*>(pf.base + (size_t)j * pf.cg_bytes + (size_t)sub * 4096 +
+                                                        (q & 3) * 1024 + lane * 16);
+        acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+      }
+      // never true for real weights; keeps the loads alive
+      if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x5a17c3e1 && acc[0] == 0x1badb002) *pf.sink = acc[1];
+    }
+    return;
+  }
   const int i = lane & 15, g = lane >> 4;
   const int n_rt = (R + 15) >> 4;
   const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
@@ -168,6 +203,22 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
     rs[a] = 0.f; rq[a] = 0.f;
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = floatx4{0, 0, 0, 0};
+  }
+  // the residual values of the tiles THIS wave finishes in the epilogue, requested now: behind the barrier the load was
+  // one more dependent round trip of a launch that is nothing but round trips (solo runs)
+  half4_t resv[(RT * NT + WAVES - 1) / WAVES];
+#pragma unroll
+  for (int q = 0; q < (RT * NT + WAVES - 1) / WAVES; ++q) resv[q] = half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  if (res) {
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        if ((a * NT + b) % WAVES != wave) continue;
+        const int row = (rt0 + a) * 16 + i, n = (ct0 + b) * 16 + 4 * g;
+        if (row < R && n < N) resv[(a * NT + b) / WAVES] = *reinterpret_cast<const half4_t*>(res + (size_t)row * ldr + n);
+      }
+    }
   }
   if (nks > 0) {
     const half8_t* wp[NT];
@@ -253,8 +304,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
       const int n = (ct0 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
       if (n >= N) continue;
       const floatx4 v4 = {v[0], v[1], v[2], v[3]};
-      half4_t r4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-      if (res) r4 = *reinterpret_cast<const half4_t*>(res + (size_t)row * ldr + n);
+      const half4_t r4 = resv[(a * NT + b) / WAVES];
       const half4_t o = dec_epilogue4<LNF>(v4, mu, rstd, s1, cf, bias, res != nullptr, r4, n, act);
       if (out) *reinterpret_cast<half4_t*>(out + (size_t)row * ldo + n) = o;
       if (out_frag) *reinterpret_cast<half4_t*>(out_frag + frag_off(row, n, N >> 5)) = o;
@@ -866,7 +916,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // per SIMD, two batches in flight.  Both return the same bits (the row's arithmetic does not depend on U), so a merged
 // run still returns what each caller gets alone.
 // ------------------------------------------------------------------------------------
-template <int U, bool PIPE, int MAXT>
+// PB (position block: prompt forward, align): the kmul rows of a chunk are kmul CONSECUTIVE POSITIONS pos_fixed + wave
+// of the chunk's beam slot 0 instead of kmul beams at one position.  Position p of the same block is a sibling row of
+// this launch: its K / V are read from the qkv buffer (the bytes the sibling writes to the cache), earlier positions
+// from the cache — the same values in the same order as position-by-position launches: the same bits.
+template <int U, bool PIPE, int MAXT, bool PB = false>
 __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __restrict__ qkv, int d, half_t* __restrict__ kc,
                                                              half_t* __restrict__ vc, int n_ctx, int cache_ctx,
                                                              int H, const uint8_t* __restrict__ kvidx2, int Kbeam, int kmul,
@@ -879,9 +933,9 @@ __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __re
   float* sp = sa_smem + (size_t)wave * 2 * n_ctx;
   int* ssrc = reinterpret_cast<int*>(sp + n_ctx);
   const int h = blockIdx.x, c = blockIdx.y;
-  const int r = c * kmul + wave, kb = wave;
-  const int step = *d_step;
-  const int pos = pos_fixed >= 0 ? pos_fixed : P - 1 + step;
+  const int r = c * kmul + wave, kb = PB ? 0 : wave;
+  const int step = PB ? 0 : *d_step;
+  const int pos = PB ? pos_fixed + wave : (pos_fixed >= 0 ? pos_fixed : P - 1 + step);
   const int slot = c * Kbeam + kb;
   const int cur = (pos_fixed >= 0) ? 0 : (step & 1);
   const uint8_t* kvidx = kvidx2 + ((size_t)cur * R_total + slot) * n_ctx;
@@ -891,7 +945,7 @@ __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __re
   const int pg = lane >> 3, cc = lane & 7;     // position group, 16-byte chunk of the 128-byte row
   // ---- A: slot table -> LDS (n_ctx is a multiple of 4: launch_self_attn checks; the row starts 4-byte aligned) ----
   for (int p4 = 4 * lane; p4 < pos; p4 += 256) {
-    const unsigned w = *reinterpret_cast<const unsigned*>(kvidx + p4);
+    const unsigned w = PB ? 0u : *reinterpret_cast<const unsigned*>(kvidx + p4);   // (prompt positions: beam slot 0)
     intx4 s4;
     s4[0] = c * Kbeam + (int)(w & 0xffu); s4[1] = c * Kbeam + (int)((w >> 8) & 0xffu);
     s4[2] = c * Kbeam + (int)((w >> 16) & 0xffu); s4[3] = c * Kbeam + (int)(w >> 24);
@@ -924,15 +978,21 @@ __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __re
   const char* vbase = reinterpret_cast<const char*>(vc + h * head_stride);
   const unsigned slot_bytes = (unsigned)(slot_stride * sizeof(half_t));
   struct Batch { half8_t row[NB]; };
-  auto fetch = [&](Batch& b, const char* base, int p0) {   // rows of positions p0 + 8 j + pg (clamped into [0, pos))
+  // PB: sib = K (d) / V (2 d) of the chunk's first row in the qkv buffer, this head; a sibling row is 3 d halves further
+  auto fetch = [&](Batch& b, const char* base, int p0, const half_t* sib) {   // rows of positions p0 + 8 j + pg (clamped into [0, pos))
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int p = p0 + 8 * j + pg;
       const int pc = p < pos ? p : pos - 1;
       const unsigned off = (unsigned)ssrc[pc] * slot_bytes + (unsigned)(pc * 128 + cc * 16);
-      b.row[j] = *reinterpret_cast<const half8_t*>(base + off);
+      if (PB && pc >= pos_fixed)
+        b.row[j] = *reinterpret_cast<const half8_t*>(sib + (size_t)(pc - pos_fixed) * 3 * d + cc * 8);
+      else
+        b.row[j] = *reinterpret_cast<const half8_t*>(base + off);
     }
   };
+  const half_t* ksib = qkv + (size_t)c * kmul * 3 * d + d + h * 64;
+  const half_t* vsib = ksib + d;
   auto score = [&](const Batch& b, int p0) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -947,26 +1007,26 @@ __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __re
   Batch b0, b1;
   // ---- B: scores ----
   if (pos > 0) {
-    fetch(b0, kbase, 0);
+    fetch(b0, kbase, 0, ksib);
     for (int p0 = 0; p0 < pos; p0 += 16 * NB) {
       if (PIPE) {
         // (unconditional prefetches — past the end they re-read the last position: a fetch under a branch makes the
         //  wait-count pass assume the worst at the join and wait for the batch just issued)
-        fetch(b1, kbase, p0 + 8 * NB);
+        fetch(b1, kbase, p0 + 8 * NB, ksib);
         score(b0, p0);
-        fetch(b0, kbase, p0 + 16 * NB);
+        fetch(b0, kbase, p0 + 16 * NB, ksib);
         score(b1, p0 + 8 * NB);
       } else {
         score(b0, p0);
         if (p0 + 8 * NB < pos) {
-          fetch(b0, kbase, p0 + 8 * NB);
+          fetch(b0, kbase, p0 + 8 * NB, ksib);
           score(b0, p0 + 8 * NB);
-          if (p0 + 16 * NB < pos) fetch(b0, kbase, p0 + 16 * NB);
+          if (p0 + 16 * NB < pos) fetch(b0, kbase, p0 + 16 * NB, ksib);
         }
       }
     }
     // ---- C: the first V batch leaves before the reductions ----
-    fetch(b0, vbase, 0);
+    fetch(b0, vbase, 0, vsib);
   }
   mx = wave_max_v(mx);
   __builtin_amdgcn_wave_barrier();
@@ -996,16 +1056,16 @@ __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __re
   };
   for (int p0 = 0; p0 < pos; p0 += 16 * NB) {
     if (PIPE) {
-      fetch(b1, vbase, p0 + 8 * NB);
+      fetch(b1, vbase, p0 + 8 * NB, vsib);
       accum(b0, p0);
-      fetch(b0, vbase, p0 + 16 * NB);
+      fetch(b0, vbase, p0 + 16 * NB, vsib);
       accum(b1, p0 + 8 * NB);
     } else {
       accum(b0, p0);
       if (p0 + 8 * NB < pos) {
-        fetch(b0, vbase, p0 + 8 * NB);
+        fetch(b0, vbase, p0 + 8 * NB, vsib);
         accum(b0, p0 + 8 * NB);
-        if (p0 + 16 * NB < pos) fetch(b0, vbase, p0 + 16 * NB);
+        if (p0 + 16 * NB < pos) fetch(b0, vbase, p0 + 16 * NB, vsib);
       }
     }
   }
@@ -1559,10 +1619,10 @@ __global__ void dec_step_advance_kernel(int* d_step) { *d_step += 1; }
 // per-token probability for align: p[r] = softmax(logits[r])[target[r]]
 __global__ __launch_bounds__(1024) void dec_token_prob_kernel(const float* __restrict__ logits, int V,
                                                               const int* __restrict__ target, float* __restrict__ out,
-                                                              int out_stride, int out_off) {
+                                                              int out_stride, int out_off, int row_mul) {
   __shared__ float red[32];
   const int b = blockIdx.x;
-  const float* lg = logits + (size_t)b * V;
+  const float* lg = logits + (size_t)b * row_mul * V;   // (position blocks: chunk b's row of this position)
   float mx = -3.0e38f;
   for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, lg[v]);
   mx = wave_max(mx);
@@ -1589,13 +1649,16 @@ __global__ __launch_bounds__(1024) void dec_token_prob_kernel(const float* __res
 __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const half_t* __restrict__ qx, int d,
                                                               const half_t* __restrict__ ck, int T, int kvp,
                                                               const int* __restrict__ heads, int n_sel,
-                                                              float* __restrict__ probs, int n_tok, int tok_idx) {
+                                                              float* __restrict__ probs, int n_tok, int tok_idx,
+                                                              int blk_n) {
   __shared__ float sq[64];
   __shared__ float red[4];
-  const int hs = blockIdx.x, b = blockIdx.y;
+  // blk_n > 1: query row y = chunk * blk_n + j is token tok_idx + j of its chunk (position blocks)
+  const int hs = blockIdx.x, row = blockIdx.y, b = row / blk_n;
+  tok_idx += row - b * blk_n;
   const int h = heads[hs];
   const int tid = threadIdx.x;
-  if (tid < 64) sq[tid] = (float)qx[(size_t)b * d + h * 64 + tid] * 0.125f;
+  if (tid < 64) sq[tid] = (float)qx[(size_t)row * d + h * 64 + tid] * 0.125f;
   __syncthreads();
   float* pr = probs + (((size_t)b * n_sel + hs) * n_tok + tok_idx) * T;
   float mx = -3.0e38f;
@@ -1639,21 +1702,31 @@ namespace fwd {
 #define DEC_BIG_MIN_ROWS 1024
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
-                  int rows, int d, const int* d_step, int pos_fixed, int P) {
-  dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, xfrag, d, d_step, pos_fixed, P);
+                  int rows, int d, const int* d_step, int pos_fixed, int P, int blk_n) {
+  dec_embed_kernel<<<rows, 128, 0, st>>>(tok, emb, pos_emb, x, xfrag, d, d_step, pos_fixed, P, blk_n);
 }
 
 template <bool LNF, int RT, int NT, int CH = 0>
 static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N,
-                    int K, int act) {
+                    int K, int act, const PfArgs* pf = nullptr) {
   const dim3 grid((N / 16 + NT - 1) / NT, ((R + 15) / 16 + RT - 1) / RT);
+  if (pf && pf->base && (grid.x & 7) == 0) {   // (the XCD of a workgroup is blockIdx.x % 8 only when grid.x % 8 == 0)
+    if (waves == 8)
+      dec_gemm_frag_kernel<8, LNF, RT, NT, CH, true><<<grid, 576, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
+                                                                            out_frag, R, N, K, act, *pf);
+    else
+      dec_gemm_frag_kernel<4, LNF, RT, NT, CH, true><<<grid, 320, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
+                                                                            out_frag, R, N, K, act, *pf);
+    return;
+  }
+  const PfArgs none = {nullptr, 0, 0, nullptr};
   if (waves == 8)
     dec_gemm_frag_kernel<8, LNF, RT, NT, CH><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R,
-                                                                   N, K, act);
+                                                                   N, K, act, none);
   else
     dec_gemm_frag_kernel<4, LNF, RT, NT, CH><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R,
-                                                                   N, K, act);
+                                                                   N, K, act, none);
 }
 
 // GEMM-shaped kernel of merged runs (dec_gemm_big_kernel), workgroup shape `cfg`; -1 when the shape does not fit.
@@ -1715,10 +1788,10 @@ static void frag_variant(hipStream_t st, bool lnf, const half_t* xf, const half_
   const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
   if (lnf)
     dec_gemm_frag_kernel<WAVES, true, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, s1, cf, nullptr, 0, out, N,
-                                                                              nullptr, R, N, K, 0);
+                                                                              nullptr, R, N, K, 0, PfArgs{nullptr, 0, 0, nullptr});
   else
     dec_gemm_frag_kernel<WAVES, false, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, nullptr, nullptr, nullptr,
-                                                                               0, out, N, nullptr, R, N, K, 0);
+                                                                               0, out, N, nullptr, R, N, K, 0, PfArgs{nullptr, 0, 0, nullptr});
 }
 int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
                                  const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
@@ -1749,38 +1822,8 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
   return 0;
 }
 
-// ------------------------------------------------------------------------------------
-// Weight prefetch for SOLO decode runs (opt-in: FWAMD_WPREFETCH=1, measured as an A/B in profiles/).  A solo step is a
-// chain of 261 dependent launches whose linears each start with a cold HBM round trip for weights nobody asked for yet
-// (a d x d linear streams 3.3 MB in 4.4-5 us = 0.7 TB/s).  The weights do not depend on anything: a shadow branch of the
-// step graph touches the NEXT linear's weight tiles while the current kernel runs, so that they sit in L2 when their
-// consumer starts.  L2 is per XCD and the hardware places workgroup b on XCD b % 8: block j here reads exactly the
-// bytes the consumer's workgroups (j, *) will read (grid.x of the register-streaming kernel, a multiple of 8 wide), so
-// every tile lands in the L2 of the XCD that will use it.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_wprefetch_kernel(const char* __restrict__ W, unsigned bytes_per_block,
-                                                           int* __restrict__ sink) {
-  const char* p = W + (size_t)blockIdx.x * bytes_per_block;
-  intx4 acc = {0, 0, 0, 0};
-#pragma unroll 8
-  for (unsigned off = threadIdx.x * 16u; off < bytes_per_block; off += 256u * 16u) {
-    const intx4 v = *reinterpret_cast<const intx4*>(p + off);
-    acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
-  }
-  // never true for real weights and never taken twice; keeps the loads alive
-  if (sink && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x5a17c3e1 && acc[0] == 0x1badb002) *sink = acc[1];
-}
-
 static bool skinny_one_tile(int R, int N) { return R <= 16 || (R <= 96 && N <= 1280); }
-
-// touches the weight tiles of the [N][K] linear a run of R rows will launch next (register-streaming kernel only)
-int launch_dec_wprefetch(hipStream_t st, const half_t* Wf, int R, int N, int K, int* sink) {
-  if (R >= DEC_BIG_MIN_ROWS || K % 32 != 0 || N % 32 != 0) return -1;
-  const int nt = skinny_one_tile(R, N) ? 1 : 2;
-  const unsigned bytes = (unsigned)nt * (unsigned)(K >> 5) * 1024u;   // a column tile = K/32 fragments of 1 KB
-  dec_wprefetch_kernel<<<N / 16 / nt, 256, 0, st>>>(reinterpret_cast<const char*>(Wf), bytes, sink);
-  return 0;
-}
+#define DEC_PF_MAX_ROWS 160   /* runs above it stream their weights for hundreds of rows: nothing to hide */
 
 // The per-layer decoder linears: K split over the waves of a workgroup, 2 x 2 tiles of 16 x 16 per workgroup
 // (measured best of {1,2} x {1,2}: profiles/r01_sweep_dec_gemm_frag_tiles.jsonl), row groups on grid.y so any
@@ -1788,22 +1831,33 @@ int launch_dec_wprefetch(hipStream_t st, const half_t* Wf, int R, int N, int K, 
 // (fragment-major, for the next GEMM) are both optional; res is row-major.
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                         int N, int K, int act) {
+                         int N, int K, int act, const NextLinear* next) {
   // Merged runs of >= DEC_BIG_MIN_ROWS rows: the LDS-staged GEMM-shaped kernel, 256 x 128 tiles for the wide linears and
   // 128 x 64 for those with 1280 columns (measured per layer at 1 520 rows: 216 -> 157 us; the register-streaming kernel
   // with 4 x 4 tiles reaches 174: profiles/r03_dec_linear_bench.txt).  Same K slices, same reduction order, same pinned
   // epilogue as the register-streaming kernel: the same bits.
   if (R >= DEC_BIG_MIN_ROWS && launch_dec_gemm_big(st, N >= 2560 ? 0 : 1, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
     return 0;
-  return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, next);
 }
 
 int dec_big_min_rows() { return DEC_BIG_MIN_ROWS; }
 
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                           int N, int K, int act) {
+                           int N, int K, int act, const NextLinear* next) {
   if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
+  // the prefetch wave (solo-size runs): which bytes the NEXT linear of this run will read, and from which XCD — its
+  // register-streaming launch has grid.x = N' / 16 / NT' column groups of NT' * K'/32 KB, group j on XCD j % 8
+  PfArgs pfa = {nullptr, 0, 0, nullptr};
+  if (next && next->w && next->sink && R <= DEC_PF_MAX_ROWS && next->K % 32 == 0 && next->N % 32 == 0) {
+    const int nt2 = skinny_one_tile(R, next->N) ? 1 : 2;
+    const int groups = next->N / 16 / nt2;
+    const unsigned cg = (unsigned)nt2 * (unsigned)(next->K >> 5) * 1024u;
+    if ((groups & 7) == 0 && (cg & 4095u) == 0)
+      pfa = PfArgs{reinterpret_cast<const char*>(next->w), cg, groups, next->sink};
+  }
+  const PfArgs* pf = pfa.base ? &pfa : nullptr;
   const int waves = K >= 2560 ? 8 : 4;   // keeps a wave's share at <= 20 k-steps = 2 chunks of loads
   // Tile grouping by row count (the arithmetic of an output does not depend on it: same bits).  One 16 x 16 tile per
   // workgroup when there are few rows — twice to four times the workgroups streaming the weights, a wave's whole K share
@@ -1812,12 +1866,12 @@ int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, c
   // DEC_BIG_MIN_ROWS (4 x 2, 2 x 4, 4 x 4 tiles measured no better there: profiles/r03_dec_linear_bench.txt, README.md)
   const bool one_tile = skinny_one_tile(R, N);
   if (one_tile) {
-    if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
+    else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
     return 0;
   }
-  if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-  else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
+  else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
   return 0;
 }
 
@@ -1897,9 +1951,18 @@ int launch_dec_logits(hipStream_t st, bool i8, const void* xf, const float* x_sc
   return 0;
 }
 
+bool self_attn_block_ok(int n_ctx, int cache_ctx, int d, int R_total) {
+  return (n_ctx & 3) == 0 && (size_t)R_total * cache_ctx * d * sizeof(half_t) < ((size_t)1 << 32);
+}
+
 void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half_t* vc, int n_ctx, int cache_ctx, int H,
                       const uint8_t* kvidx2, int Kbeam, int kmul, half_t* out, int rows, const int* d_step,
-                      int pos_fixed, int P, int R_total, int frag) {
+                      int pos_fixed, int P, int R_total, int frag, int blk_n) {
+  if (blk_n > 0) {   // a block of blk_n consecutive positions per chunk (self_attn_block_ok holds: the caller checked)
+    dec_self_attn2_kernel<1, true, 1024, true><<<dim3(H, rows / blk_n), blk_n * 64, (size_t)blk_n * 2 * n_ctx * sizeof(float), st>>>(
+        qkv, d, kc, vc, n_ctx, cache_ctx, H, kvidx2, Kbeam, blk_n, out, d_step, pos_fixed, P, R_total, frag);
+    return;
+  }
   // one workgroup per (head, chunk), one wave per row of the chunk (kmul <= 16); LDS: scores + source slots per wave
   const dim3 grid(H, rows / kmul);
   const size_t lds = (size_t)kmul * 2 * n_ctx * sizeof(float);
@@ -1953,14 +2016,15 @@ void launch_beam_update(hipStream_t st, const GenDev& gp, const float* cand_val,
 void launch_step_advance(hipStream_t st, int* d_step) { dec_step_advance_kernel<<<1, 1, 0, st>>>(d_step); }
 
 void launch_token_prob(hipStream_t st, const float* logits, int V, const int* target, float* out, int out_stride,
-                       int out_off, int rows) {
-  dec_token_prob_kernel<<<rows, 1024, 0, st>>>(logits, V, target, out, out_stride, out_off);
+                       int out_off, int rows, int row_mul) {
+  dec_token_prob_kernel<<<rows, 1024, 0, st>>>(logits, V, target, out, out_stride, out_off, row_mul);
 }
 
 void launch_cross_probs(hipStream_t st, const half_t* qx, int d, const half_t* ck, int T, int kvp, const int* heads,
-                        int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B) {
-  dec_cross_probs_kernel<<<dim3(n_layer_heads, B), 256, 0, st>>>(qx, d, ck, T, kvp, heads, n_sel, probs, n_tok,
-                                                                 tok_idx);
+                        int n_layer_heads, int n_sel, float* probs, int n_tok, int tok_idx, int B, int blk_n) {
+  const int bn = blk_n > 0 ? blk_n : 1;
+  dec_cross_probs_kernel<<<dim3(n_layer_heads, B * bn), 256, 0, st>>>(qx, d, ck, T, kvp, heads, n_sel, probs, n_tok,
+                                                                      tok_idx, bn);
 }
 
 }  // namespace fwd

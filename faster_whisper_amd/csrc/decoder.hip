@@ -76,6 +76,7 @@ struct GenWorkspace {
   half_t *x = nullptr, *qkv = nullptr, *att = nullptr, *qc = nullptr, *ffn = nullptr;
   float* logits = nullptr;               // [R][V]
   int* prompt_dev = nullptr;             // [NT][max(R, B)]
+  int* prompt_blk = nullptr;             // the same tokens in position-block order: [block][chunk][position of the block]
   int* cur_tok = nullptr;                // [R]
   int* hist2 = nullptr;                  // [2][R][NT]
   float* cum2 = nullptr;                 // [2][R]
@@ -83,6 +84,7 @@ struct GenWorkspace {
   float* cand_val = nullptr;             // [R][32]
   int* cand_tok = nullptr;
   int *done = nullptr, *n_done = nullptr, *n_fin = nullptr, *fin_tok = nullptr, *fin_len = nullptr;
+  int* pf_sink = nullptr;   // never written (dec_kernels.hip: PfArgs)
   float *fin_score = nullptr, *fin_cum = nullptr;
   int* d_step = nullptr;
   float* no_speech = nullptr;
@@ -241,11 +243,6 @@ static int gen_workspace_build(Model* m) {
   FW_CHECK_ARG(R <= 2048, "decode_batch * max_beam must be <= 2048 (got %zu)", R);
   FW_HIP(hipSetDevice(m->device));
   if (!m->dec_stream) FW_HIP(hipStreamCreateWithFlags(&m->dec_stream, hipStreamNonBlocking));
-  if (!m->pf_stream) {
-    FW_HIP(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
-    FW_HIP(hipEventCreateWithFlags(&m->pf_fork, hipEventDisableTiming));
-    FW_HIP(hipEventCreateWithFlags(&m->pf_join, hipEventDisableTiming));
-  }
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
   A(g->slot_map, R);
@@ -254,7 +251,7 @@ static int gen_workspace_build(Model* m) {
   A(g->x, R * d); A(g->qkv, R * 3 * d); A(g->att, R * d); A(g->qc, R * d);
   A(g->ffn, R * 4 * d);
   A(g->logits, R * c.n_vocab);
-  A(g->prompt_dev, NT * R);
+  A(g->prompt_dev, NT * R); A(g->prompt_blk, NT * R);
   A(g->cur_tok, R);
   A(g->hist2, 2 * R * NT);
   A(g->cum2, 2 * R);
@@ -262,7 +259,7 @@ static int gen_workspace_build(Model* m) {
   A(g->cand_val, R * 32);
   A(g->cand_tok, R * 32);
   // per-chunk state is sized by ROWS: random sampling runs every hypothesis as its own beam-1 chunk
-  A(g->done, R); A(g->n_done, 1); A(g->n_fin, R);
+  A(g->done, R); A(g->n_done, 1); A(g->n_fin, R); A(g->pf_sink, 1);
   A(g->fin_tok, R * FIN_CAP * NT); A(g->fin_len, R * FIN_CAP);
   A(g->fin_score, R * FIN_CAP); A(g->fin_cum, R * FIN_CAP);
   A(g->d_step, 1);
@@ -313,7 +310,7 @@ void gen_workspace_free(Model* m) {
   void* ptrs[] = {g->slot_map, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_bits,
-                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag, g->xn_frag};
+                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag, g->xn_frag, g->pf_sink, g->prompt_blk};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -376,6 +373,11 @@ struct StepCfg {
   bool beam_tail;      // logits rules + beam update + step advance
   const int* done;     // per-chunk done flags for cross-attn early exit
   int kv_slot0 = 0;    // align: first pool slot of the call's block (its chunks are contiguous there)
+  // POSITION BLOCK (prompt forward, align): blk_n > 0 — rows = B * blk_n, row = chunk * blk_n + j is position
+  // pos_fixed + j of the chunk's beam slot 0, kmul = blk_n.  One pass over the decoder for blk_n positions: the weights,
+  // and the chunk's cross-attention K / V^T (the dominant HBM stream), are read once for all of them.
+  int blk_n = 0;
+  int nospeech_off = 0; // row of the chunk's block whose logits feed the no-speech kernel
   // align extras
   const int* sel_heads_dev = nullptr;   // [n_sel_total] head ids, grouped per layer
   const int* sel_layer_off = nullptr;   // host: [L+1] offsets into sel_heads
@@ -390,18 +392,43 @@ struct StepCfg {
     }                                                                   \
   } while (0)
 
-// weight prefetch of solo runs: FWAMD_WPREFETCH=1, or fw_test_knob(3, 0 / 1) for an A/B inside one process
+// Weight prefetch of solo runs (knob 3 / FWAMD_WPREFETCH, default ON): every register-streaming linear of a run of
+// <= 160 rows carries one extra wave per workgroup that touches the NEXT linear's weight tiles into the L2 of the XCD
+// that will read them (dec_kernels.hip: dec_gemm_frag_kernel<.., PF>).  Round 5 first tried it as a shadow branch of the
+// step graph (a prefetch kernel per linear on a second captured stream): 2.3x SLOWER — every fork edge of a HIP graph
+// costs ~10 us (profiles/r05_ab_wprefetch_shadow_branch.jsonl) — so the prefetch rides inside the producer's launch.
 static std::atomic<int> g_wprefetch{-1};
-static bool wprefetch_on() {
+bool wprefetch_on() {
   int v = g_wprefetch.load(std::memory_order_relaxed);
   if (v < 0) {
     const char* e = getenv("FWAMD_WPREFETCH");
-    v = (e && atoi(e) != 0) ? 1 : 0;
+    v = (e && atoi(e) == 0) ? 0 : 1;
     g_wprefetch.store(v);
   }
   return v != 0;
 }
 void set_wprefetch(int on) { g_wprefetch.store(on ? 1 : 0); fwd::bump_kernel_forms_epoch(); }
+
+// position blocks for the prompt forward and align (knob 4 / FWAMD_POS_BLOCKS, default ON; 0: one position per pass,
+// rounds 1-4): the same bits either way (tests/test_gpu_model.py::test_position_blocks_same_bits)
+static std::atomic<int> g_pos_blocks{-1};
+static bool pos_blocks_on() {
+  int v = g_pos_blocks.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("FWAMD_POS_BLOCKS");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+    g_pos_blocks.store(v);
+  }
+  return v != 0;
+}
+void set_pos_blocks(int on) { g_pos_blocks.store(on ? 1 : 0); }
+// positions per block for a pass over `chunks` chunks: the workspace holds g->R rows, the cross-attention kernel takes
+// <= 16 queries per chunk
+static int pos_block_size(const Model* m, const GenWorkspace* g, const GenDev& gp, int chunks) {
+  if (!pos_blocks_on() || chunks < 1) return 1;
+  if (!fwd::self_attn_block_ok(g->NT, gp.ctx, m->cfg.d_model, gp.R)) return 1;
+  return std::max(1, std::min(16, g->R / chunks));
+}
 
 // One decoder forward over `rows` rows.  Everything that varies from step to step lives in HBM (d_step, beam
 // tables), and everything a captured graph bakes in by value is part of GenDev (the graph key).
@@ -417,7 +444,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   {
     ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
     fwd::launch_embed(st, s.tok, m->tok_emb, m->dec_pos, g->x, i8 ? nullptr : g->x_frag, rows, d, g->d_step,
-                      s.pos_fixed, s.P);
+                      s.pos_fixed, s.P, s.blk_n);
   }
   // int8_float16 (K25): the row quantiser (fused with the LayerNorm where one feeds the linear) writes the int8
   // rows fragment-major, then the int8 skinny GEMM de-quantises in its epilogue
@@ -427,31 +454,16 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   };
   // fp16: xin is the fragment-major copy of the input; the residual stream is kept row-major too (residual
   // adds), the FFN hidden only fragment-major; LayerNorms are folded into qkv / cross-q / ffn1
+  // nxt: the linear this run launches next — its weights are touched into L2 by an extra wave of THIS launch (solo-size
+  // runs only; knob 3)
+  const bool pf_on = wprefetch_on();
   auto lin_f = [&](const half_t* xin_frag, const LinearW& L, const half_t* res, half_t* outp, half_t* outp_frag,
-                   int act) -> int {
+                   int act, const LinearW* nxt = nullptr) -> int {
+    const fwd::NextLinear nl = {nxt ? nxt->w : nullptr, nxt ? nxt->N : 0, nxt ? nxt->K : 0, g->pf_sink};
     return fwd::launch_dec_gemm_frag(st, xin_frag, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, outp_frag, rows, L.N,
-                                     L.K, act);
+                                     L.K, act, (pf_on && nxt) ? &nl : nullptr);
   };
   const int frag = i8 ? 0 : 1;
-  // ---- weight prefetch one linear ahead on a shadow branch of the step graph (opt-in, solo-size fp16 runs, only while
-  //      the step is being CAPTURED: the eager steps of a run are few).  pf(L) is called right before the launch of the
-  //      kernel that precedes linear L's predecessor... concretely: before kernel k, with L = the first linear after k;
-  //      the branch forks from the completion of kernel k - 1, so the prefetch runs BESIDE kernel k and the main chain
-  //      never waits for it (the branch is joined once, at the end of the step: a capture must end with one stream).
-  bool pf_on = false;
-  {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (wprefetch_on() && !i8 && rows <= 160 && m->pf_stream && hipStreamIsCapturing(st, &cs) == hipSuccess)
-      pf_on = cs == hipStreamCaptureStatusActive;
-  }
-  bool pf_used = false;
-  auto pf = [&](const LinearW& L) {
-    if (!pf_on) return;
-    if (hipEventRecord(m->pf_fork, st) != hipSuccess) return;
-    if (hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0) != hipSuccess) return;
-    fwd::launch_dec_wprefetch(m->pf_stream, L.w, rows, L.N, L.K, nullptr);
-    pf_used = true;
-  };
   // fp16, explicit-LayerNorm order (Model::ln_unfold == 2): the LayerNorm is its own kernel, its fp16 output (fragment-
   // major) feeds the plain weight — the rounding points of an fp16 LayerNorm followed by an fp16 GEMM
   const bool unf = !i8 && m->ln_unfold >= 2;
@@ -467,18 +479,16 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     half_t* vc = g->sv + (size_t)l * gp.cache_rows * gp.ctx * d;
     const half_t* ck = pool->ck + (size_t)l * pool->n_slots() * d * kvp;
     const half_t* cvt = pool->cvt + (size_t)l * pool->n_slots() * d * kvp;
-    pf(L.out);
     {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
       else if (unf) DG(lin_u(L.ln1, L.qkv_p, g->qkv, nullptr, 0));
-      else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
+      else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0, &L.out));
     }
-    pf(L.cq);
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0, st);
       fwd::launch_self_attn(st, g->qkv, d, kc, vc, NT, gp.ctx, H, g->kvidx2, gp.K, s.kmul, frag ? g->att_frag : g->att, rows,
-                            g->d_step, s.pos_fixed, s.P, gp.R, frag);
+                            g->d_step, s.pos_fixed, s.P, gp.R, frag, s.blk_n);
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 2.0 * d * d, 2.0 * 2.0 * d * d, st);
@@ -486,41 +496,38 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
         DG(lin_q(g->att, nullptr, L.out, g->x, g->x, 0));
         DG(lin_q(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
       } else {
-        DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0));
+        DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0, unf ? nullptr : &L.cq));
         if (unf) DG(lin_u(L.ln2, L.cq_p, g->qc, nullptr, 0));
-        else DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0));
+        else DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0, &L.cout));
       }
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
       ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
       const int off = s.sel_layer_off[l], n = s.sel_layer_off[l + 1] - off;
       fwd::launch_cross_probs(st, g->qc, d, ck + (size_t)s.kv_slot0 * d * kvp, T, kvp, s.sel_heads_dev + off, n, s.n_sel_total,
-                              s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B);
+                              s.probs + (size_t)off * s.n_tok * T, s.n_tok, s.tok_idx, s.B, s.blk_n);
     }
-    pf(L.cout);
     {
       ProfScope ps(m, PF_DEC_CROSS_ATTN, 4.0 * rows * (double)T * d, 4.0 * (s.B / gp.kv_div) * (double)T * d, st);
       fwd::launch_cross_attn(st, g->qc, d, ck, cvt, T, kvp, s.kmul, frag ? g->att_frag : g->att, s.B, H, s.done,
                              gp.kv_div, frag, g->slot_map);
     }
-    pf(L.ffn1);
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d, st);
       if (i8) DG(lin_q(g->att, nullptr, L.cout, g->x, g->x, 0));
-      else DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0));
+      else DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0, unf ? nullptr : &L.ffn1));
     }
-    pf(L.ffn2);
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
       else if (unf) DG(lin_u(L.ln3, L.ffn1_p, nullptr, g->ffn_frag, 1));
-      else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
+      else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1, &L.ffn2));
     }
-    if (l + 1 < c.n_dec_layers) pf(m->dec[l + 1].qkv);
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
-      else DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0));
+      else DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0,
+                    (!unf && l + 1 < c.n_dec_layers) ? &m->dec[l + 1].qkv : nullptr));
     }
   }
   if (s.need_logits || s.beam_tail) {
@@ -540,9 +547,9 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   }
   if (s.nospeech_rowmul > 0) {
     ProfScope ps(m, PF_DEC_MISC, 0, 0, st);
-    fwd::launch_nospeech(st, g->logits, c.n_vocab, s.nospeech_rowmul, c.tok_no_speech, g->no_speech, s.B);
+    fwd::launch_nospeech(st, g->logits + (size_t)s.nospeech_off * c.n_vocab, c.n_vocab, s.nospeech_rowmul,
+                         c.tok_no_speech, g->no_speech, s.B);
   }
-  if (s.beam_tail) pf(m->dec[0].qkv);   // the next step's first linear, beside the logits rules
   if (s.beam_tail) {
     ProfScope ps(m, PF_DEC_SAMPLE, 0, 8.0 * rows * c.n_vocab, st);
     fwd::launch_logits_process(st, gp, g->logits, g->sup_bits, g->hist2, g->cum2, g->d_step, g->done, g->cand_val,
@@ -550,10 +557,6 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     fwd::launch_beam_update(st, gp, g->cand_val, g->cand_tok, g->hist2, g->cum2, g->kvidx2, g->cur_tok, g->d_step,
                             g->done, g->n_done, g->n_fin, g->fin_tok, g->fin_len, g->fin_score, g->fin_cum);
     fwd::launch_step_advance(st, g->d_step);
-  }
-  if (pf_used) {   // the shadow branch rejoins: a capture ends with every forked stream joined
-    FW_HIP(hipEventRecord(m->pf_join, m->pf_stream));
-    FW_HIP(hipStreamWaitEvent(st, m->pf_join, 0));
   }
   return FW_OK;
 }
@@ -730,14 +733,40 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
   FW_HIP(hipStreamSynchronize(st));   // the host buffers above are locals
 
   // ---- prompt forward (all but the last token): Bx rows, beam slot 0 of every chunk ----
-  for (int pos = 0; pos < P - 1; ++pos) {
-    StepCfg s;
-    s.rows = Bx; s.kmul = 1; s.B = Bx; s.pos_fixed = pos; s.P = P; s.tok = g->prompt_dev + (size_t)pos * Bx;
-    s.need_logits = (pos == sot_pos) && want_nsp;
-    s.nospeech_rowmul = s.need_logits ? 1 : 0;
-    s.beam_tail = false;
-    s.done = g->done;
-    if ((rc = run_step(m, gp, s))) return rc;
+  //      in blocks of up to 16 positions per pass (one pass for the 3 positions of the usual 4-token prompt; a prompt that
+  //      carries 223 tokens of previous text takes 14 passes instead of 223)
+  {
+    const int nbmax = pos_block_size(m, g, gp, Bx);
+    std::vector<int> blk_tok;
+    if (nbmax > 1 && P - 1 > 1) {
+      blk_tok.reserve((size_t)(P - 1) * Bx);
+      for (int pos = 0; pos < P - 1;) {
+        const int nb = std::min(nbmax, P - 1 - pos);
+        for (int b = 0; b < Bx; ++b)
+          for (int j = 0; j < nb; ++j) blk_tok.push_back(ptok[(size_t)(pos + j) * Bx + b]);
+        pos += nb;
+      }
+      FW_HIP(hipMemcpyAsync(g->prompt_blk, blk_tok.data(), blk_tok.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      FW_HIP(hipStreamSynchronize(st));
+    }
+    for (int pos = 0; pos < P - 1;) {
+      const int nb = blk_tok.empty() ? 1 : std::min(nbmax, P - 1 - pos);
+      StepCfg s;
+      s.B = Bx; s.pos_fixed = pos; s.P = P;
+      s.need_logits = sot_pos >= pos && sot_pos < pos + nb && want_nsp;
+      s.beam_tail = false;
+      s.done = g->done;
+      if (nb > 1) {
+        s.rows = Bx * nb; s.kmul = nb; s.blk_n = nb; s.tok = g->prompt_blk + (size_t)pos * Bx;
+        s.nospeech_rowmul = s.need_logits ? nb : 0;
+        s.nospeech_off = s.need_logits ? sot_pos - pos : 0;
+      } else {
+        s.rows = Bx; s.kmul = 1; s.tok = blk_tok.empty() ? g->prompt_dev + (size_t)pos * Bx : g->prompt_blk + (size_t)pos * Bx;
+        s.nospeech_rowmul = s.need_logits ? 1 : 0;
+      }
+      if ((rc = run_step(m, gp, s))) return rc;
+      pos += nb;
+    }
   }
   if ((rc = check_launch("prompt forward"))) return rc;
 
@@ -1377,19 +1406,52 @@ extern "C" int32_t fw_align(fw_model* fm, const fw_tensor* enc_t, const int32_t*
   memset(&gp, 0, sizeof(gp));
   gp.B = B; gp.K = m->max_beam; gp.R = g->R; gp.P = max_tok; gp.V = c.n_vocab; gp.n_text_ctx = g->NT; gp.kv_div = 1;
   gp.ctx = std::min(g->NT, (max_tok + 7) / 8 * 8); gp.cache_rows = B * m->max_beam;   // <= EB * K * NT <= self_cap
-  for (int pos = 0; pos < max_tok; ++pos) {
+  // teacher forcing: every position is known up front, so the text goes through the decoder in blocks of up to 16
+  // positions per pass (a 100-token segment: 7 passes instead of 100)
+  const int nbmax = pos_block_size(m, g, gp, B);
+  if (nbmax > 1) {
+    std::vector<int> blk_tok;
+    blk_tok.reserve((size_t)max_tok * B);
+    for (int pos = 0; pos < max_tok;) {
+      const int nb = std::min(nbmax, max_tok - pos);
+      for (int b = 0; b < B; ++b)
+        for (int j = 0; j < nb; ++j) blk_tok.push_back(ptok[(size_t)(pos + j) * B + b]);
+      pos += nb;
+    }
+    he = hipMemcpyAsync(g->prompt_blk, blk_tok.data(), blk_tok.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) {
+      cleanup();
+      set_error("align setup failed: %s", hipGetErrorString(he));
+      return FW_ERUNTIME;
+    }
+  }
+  for (int pos = 0; pos < max_tok;) {
+    const int nb = std::min(nbmax, max_tok - pos);
     StepCfg s;
-    s.rows = B; s.kmul = 1; s.B = B; s.pos_fixed = pos; s.P = max_tok; s.tok = g->prompt_dev + (size_t)pos * B;
+    s.B = B; s.pos_fixed = pos; s.P = max_tok;
+    if (nbmax > 1) {   // (a last block of one position has the same layout either way)
+      s.rows = B * nb; s.kmul = nb; s.blk_n = nb > 1 ? nb : 0; s.tok = g->prompt_blk + (size_t)pos * B;
+    } else {
+      s.rows = B; s.kmul = 1; s.tok = g->prompt_dev + (size_t)pos * B;
+    }
     bool any_target = false;
-    for (int b = 0; b < B; ++b) any_target |= target[(size_t)pos * B + b] >= 0;
+    for (int j = 0; j < nb; ++j)
+      for (int b = 0; b < B; ++b) any_target |= target[(size_t)(pos + j) * B + b] >= 0;
     s.need_logits = any_target;
     s.nospeech_rowmul = 0; s.beam_tail = false; s.done = g->zero_done;
     s.sel_heads_dev = heads_dev; s.sel_layer_off = layer_off.data(); s.probs = probs; s.n_sel_total = n_sel;
     s.kv_slot0 = kv_slot0;
     s.n_tok = max_tok; s.tok_idx = pos;
     if ((rc = run_step(m, gp, s))) { cleanup(); return rc; }
-    if (any_target)
-      fwd::launch_token_prob(st, g->logits, c.n_vocab, target_dev + (size_t)pos * B, tprob, max_tok, pos, B);
+    for (int j = 0; j < nb && any_target; ++j) {
+      bool tj = false;
+      for (int b = 0; b < B; ++b) tj |= target[(size_t)(pos + j) * B + b] >= 0;
+      if (tj)
+        fwd::launch_token_prob(st, g->logits + (size_t)j * c.n_vocab, c.n_vocab, target_dev + (size_t)(pos + j) * B, tprob,
+                               max_tok, pos + j, B, nb);
+    }
+    pos += nb;
   }
   {
     dim3 g1((T + 127) / 128, n_sel, B);

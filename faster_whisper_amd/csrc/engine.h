@@ -200,9 +200,6 @@ struct Model {
   void* self = nullptr;         // the fw_model this Model lives in
   Model* blob_owner = nullptr;  // the model whose blob this one borrows (fw_model_create_from_blob_dev on fw_model_blob)
   hipStream_t dec_stream = nullptr;
-  // shadow branch of the solo step graph (FWAMD_WPREFETCH=1): weight prefetch one linear ahead (decoder.hip: run_step)
-  hipStream_t pf_stream = nullptr;
-  hipEvent_t pf_fork = nullptr, pf_join = nullptr;
   std::mutex dec_mu;
   DecodeGroup grp;
 
@@ -247,7 +244,9 @@ int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, ha
 int run_encoder(Model* m, int B, half_t* out);
 
 // decoder entry points (decoder.hip)
-void set_wprefetch(int on);                   // fw_test_knob(3, ..): the weight-prefetch branch of solo step graphs
+void set_wprefetch(int on);                   // fw_test_knob(3, ..): the weight-prefetch wave of solo-size linears
+bool wprefetch_on();
+void set_pos_blocks(int on);                  // fw_test_knob(4, ..): position blocks for the prompt forward and align
 uint64_t next_tensor_id();
 int gen_workspace_ensure(Model* dm);          // creates dm's decode workspace on first use (caller holds dm->dec_mu)
 void gen_workspace_free(Model* m);

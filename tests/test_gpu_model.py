@@ -404,26 +404,66 @@ def test_self_attention_forms_return_the_same_bits(setup):
     print(f"[{cfg.name}] self-attention forms 1 / 2 / 3 / auto: identical ids, scores and no-speech bits over 3 configurations")
 
 
-def test_weight_prefetch_branch_same_results(setup):
-    """Round 5, opt-in (FWAMD_WPREFETCH=1 / fw_test_knob 3): the captured step graph of a solo run gets a shadow branch
-    that touches the next linear's weight tiles beside the current kernel.  It computes nothing: results must not move,
-    and the two-stream capture (fork per linear, one join per step) must instantiate and replay."""
+def test_weight_prefetch_wave_same_results(setup):
+    """Round 5 (fw_test_knob 3 / FWAMD_WPREFETCH, default on): every register-streaming decoder linear of a solo-size run
+    carries one extra wave per workgroup that touches the NEXT linear's weight tiles into L2 (dec_gemm_frag_kernel<.., PF>).
+    The wave computes nothing and takes no barrier: results must not move by a bit, eagerly and as a replayed graph."""
     from faster_whisper_amd import _lib
     from faster_whisper_amd.backend import StorageView
     cfg, model, oracle, feats = setup
     lib = _lib.load()
     enc = model.encode(StorageView.from_array(feats))
-    prompt = _prompt(cfg, True)
-    kw = dict(beam_size=5, max_length=len(prompt) + 30, suppress_blank=True, suppress_tokens=_suppress(cfg),
-              max_initial_timestamp_index=50)
     res = {}
     try:
         for on in (0, 1, 0):
             _lib.check(lib.fw_test_knob(3, on))
-            got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
-            got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)   # the replay
-            res.setdefault(on, []).append([(g.sequences_ids, g.scores, g.no_speech_prob) for g in got])
+            outs = []
+            for beam, ts in ((5, True), (1, False)):
+                prompt = _prompt(cfg, ts)
+                kw = dict(beam_size=beam, max_length=len(prompt) + 30, suppress_blank=True, suppress_tokens=_suppress(cfg),
+                          max_initial_timestamp_index=50)
+                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)   # the replay
+                outs.append([(g.sequences_ids, g.scores, g.no_speech_prob) for g in got])
+            res.setdefault(on, []).append(outs)
     finally:
-        _lib.check(lib.fw_test_knob(3, 0))
+        _lib.check(lib.fw_test_knob(3, 1))
     assert res[1][0] == res[0][0] == res[0][1]
-    print(f"[{cfg.name}] weight-prefetch branch on / off: identical results")
+    print(f"[{cfg.name}] weight-prefetch wave on / off: identical results")
+
+
+def test_position_blocks_same_bits(setup):
+    """Round 5 (fw_test_knob 4, default on): the prompt forward of `generate` and the teacher-forced pass of `align` go
+    through the decoder in blocks of up to 16 positions per pass (rows = chunks x positions; a sibling position's K / V
+    are read from the qkv buffer instead of the cache) instead of one position per pass.  Every row keeps its arithmetic,
+    so nothing may move by a bit: a 4-token prompt (one block of 3), a prompt with 37 tokens of previous text (blocks of
+    16 + 16 + 4 with the <sot> row — the no-speech probability — inside the third), beam and greedy; align over texts
+    of 5 .. 40 tokens (the engine pads to the longest: several blocks, ragged ends)."""
+    from faster_whisper_amd import _lib
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    lib = _lib.load()
+    enc = model.encode(StorageView.from_array(feats))
+    rng = np.random.default_rng(44)
+    prev = [cfg.sot_prev] + rng.integers(10, 300, size=36).tolist()
+    text = [rng.integers(10, 300, size=n).tolist() for n in (33, 5, 40)]
+    num_frames = [3000, 1250, 2000]
+    res = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.fw_test_knob(4, on))
+            out = []
+            for prompt, beam in ((_prompt(cfg, True), 5), (prev + _prompt(cfg, False), 5), (prev + _prompt(cfg, True), 1)):
+                kw = dict(beam_size=beam, max_length=len(prompt) + 12, suppress_blank=True, suppress_tokens=_suppress(cfg),
+                          max_initial_timestamp_index=50)
+                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+                out.append([(g.sequences_ids, [np.float32(s).tobytes() for s in g.scores],
+                             np.float32(g.no_speech_prob).tobytes()) for g in got])
+            al = model.align(enc, cfg.sot_sequence, text, num_frames, median_filter_width=7)
+            out.append([(a.alignments, np.asarray(a.text_token_probs, np.float32).tobytes()) for a in al])
+            res[on] = out
+    finally:
+        _lib.check(lib.fw_test_knob(4, 1))
+    for i, (a, b) in enumerate(zip(res[0], res[1])):
+        assert a == b, f"position blocks changed result set {i}"
+    print(f"[{cfg.name}] position blocks on / off: identical ids, scores, no-speech, alignments and token probabilities")
