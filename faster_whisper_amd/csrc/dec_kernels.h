@@ -46,16 +46,13 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
 // rows from which launch_dec_gemm_frag hands a decode run's linears to the GEMM-shaped kernel
 int dec_big_min_rows();
 // frag = 1: `out` is a fragment-major [rows/16][d/32][64][8] buffer (input of launch_dec_gemm_frag)
-// next (optional): the linear the run launches after this one — a solo-size launch touches its weights into L2 with
-// one extra wave per workgroup (dec_kernels.hip: PF); results do not depend on it
-struct NextLinear { const half_t* w; int N, K; int* sink; };
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                         int N, int K, int act, const NextLinear* next = nullptr);
+                         int N, int K, int act);
 // the skinny kernel whatever the row count (launch_dec_gemm_frag hands merged runs to the GEMM-shaped kernel)
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                           int N, int K, int act, const NextLinear* next = nullptr);
+                           int N, int K, int act);
 // ... with an explicit tile grouping (1: one 16 x 16 tile per workgroup, 2: 2 x 2 tiles)
 int launch_dec_gemm_skinny_tiles(hipStream_t st, int tiles, const half_t* xf, const half_t* Wf, const half_t* bias,
                                  const float* s1, const float* cf, const half_t* res, int ldr, half_t* out, int ldo,

@@ -142,24 +142,17 @@ static __device__ __forceinline__ half4_t dec_epilogue4_i8(const int (&v)[4], fl
 //     runs (320-1 680 rows) that L2 traffic, not HBM, is what bounds the kernel (profiles/NOTES.md);
 //   * fixed-order reduction of the WAVES partial tiles through LDS, epilogue spread over the waves.
 // ------------------------------------------------------------------------------------
-//   * PF (solo-size runs, round 5): one EXTRA wave per workgroup that computes nothing — it touches this workgroup's share of
-//     the NEXT linear's weights (PfArgs) and leaves.  A solo step is a chain of 261 dependent launches whose linears each
-//     start with a cold HBM round trip for weights that depend on nothing; touched one launch ahead they sit in L2 when
-//     their consumer starts.  L2 is per XCD and the hardware places workgroup w on XCD w % 8: the consumer's column group j
-//     runs on XCD j % 8 (its grid.x is a multiple of 8), so it is touched by workgroups of this launch with w % 8 == j % 8, in
-//     units of 4 KB dealt round-robin.  The wave has its own vmcnt, so the other waves never wait for its loads; it takes
-//     no barrier (a wave that has ended is not counted).
-struct PfArgs {
-  const char* base;     // next linear's fragment-major weights; null: nothing to touch
-  unsigned cg_bytes;    // bytes of one column group of the consumer (NT' column tiles x K'/32 fragments of 1 KB)
-  int groups;           // column groups of the consumer (its grid.x)
-  int* sink;            // an int in HBM nobody reads (keeps the loads alive)
-};
-template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0, bool PF = false>
-__global__ __launch_bounds__((WAVES + (PF ? 1 : 0)) * 64) void dec_gemm_frag_kernel(
+// (Round 5 measured two ways of touching the NEXT linear's weights ahead of its launch for solo runs — a prefetch kernel on a
+//  shadow branch of the step graph, and an extra wave inside this kernel that reads the consumer's tiles on the XCD that
+//  will use them.  Both lost: a fork edge of a HIP graph costs ~10 us (2.3x slower steps), and the L2 does not keep clean
+//  lines across a kernel boundary (the acquire that makes other XCDs' writes visible drops them), so the consumer
+//  re-fetches anyway and the prefetch only doubles the traffic: 192 -> 289 ms single utterance.
+//  profiles/r05_ab_wprefetch_shadow_branch.jsonl, r05_ab_wprefetch_wave.jsonl; the code is in the history: commits eeb074e (wave) and d097c11^ (branch))
+template <int WAVES, bool LNF, int RT, int NT, int CH_ = 0>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
-    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act, PfArgs pf) {
+    half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act) {
   // RT x NT tiles of 16 x 16 per workgroup (larger tiles re-use the x / W fragments in registers and cut the L2
   // re-reads at the price of fewer, fatter workgroups: launch_dec_gemm_frag_variant / profiles/dec_linear_bench.py)
   __shared__ float red[WAVES][RT * NT][64][4];
@@ -167,27 +160,6 @@ __global__ __launch_bounds__((WAVES + (PF ? 1 : 0)) * 64) void dec_gemm_frag_ker
   constexpr int CH = CH_ ? CH_ : 20 / (RT + NT);   // k-steps in flight per wave: (RT + NT) * CH * 16 B per lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (PF && wave == WAVES) {   // the prefetch wave
-    if (pf.base) {
-      const int w = blockIdx.x + gridDim.x * blockIdx.y;      // this workgroup runs on XCD w % 8
-      const int xcd = w & 7, t = w >> 3, T = (gridDim.x * gridDim.y + 7 - xcd) >> 3;   // T: workgroups on that XCD
-      const int S = pf.cg_bytes >> 12;                        // 4 KB units per column group
-      const int units = ((pf.groups - xcd + 7) >> 3) * S;     // ... of the groups j = xcd, xcd + 8, ...
-      const int mine = units > t ? (units - t + T - 1) / T : 0;
-      intx4 acc = {0, 0, 0, 0};
-#pragma unroll 16
-      for (int q = 0; q < mine * 4; ++q) {
-        const int u = t + (q >> 2) * T;
-        const int j = xcd + 8 * (u / S), sub = u - (u / S) * S;
-        const intx4 v = *reinterpret_cast<const intx4*>(pf.base + (size_t)j * pf.cg_bytes + (size_t)sub * 4096 +
-                                                        (q & 3) * 1024 + lane * 16);
-        acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
-      }
-      // never true for real weights; keeps the loads alive
-      if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x5a17c3e1 && acc[0] == 0x1badb002) *pf.sink = acc[1];
-    }
-    return;
-  }
   const int i = lane & 15, g = lane >> 4;
   const int n_rt = (R + 15) >> 4;
   const int ct0 = blockIdx.x * NT, rt0 = blockIdx.y * RT;
@@ -1709,24 +1681,14 @@ void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_
 template <bool LNF, int RT, int NT, int CH = 0>
 static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                     const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N,
-                    int K, int act, const PfArgs* pf = nullptr) {
+                    int K, int act) {
   const dim3 grid((N / 16 + NT - 1) / NT, ((R + 15) / 16 + RT - 1) / RT);
-  if (pf && pf->base && (grid.x & 7) == 0) {   // (the XCD of a workgroup is blockIdx.x % 8 only when grid.x % 8 == 0)
-    if (waves == 8)
-      dec_gemm_frag_kernel<8, LNF, RT, NT, CH, true><<<grid, 576, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
-                                                                            out_frag, R, N, K, act, *pf);
-    else
-      dec_gemm_frag_kernel<4, LNF, RT, NT, CH, true><<<grid, 320, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
-                                                                            out_frag, R, N, K, act, *pf);
-    return;
-  }
-  const PfArgs none = {nullptr, 0, 0, nullptr};
   if (waves == 8)
     dec_gemm_frag_kernel<8, LNF, RT, NT, CH><<<grid, 512, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R,
-                                                                   N, K, act, none);
+                                                                   N, K, act);
   else
     dec_gemm_frag_kernel<4, LNF, RT, NT, CH><<<grid, 256, 0, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R,
-                                                                   N, K, act, none);
+                                                                   N, K, act);
 }
 
 // GEMM-shaped kernel of merged runs (dec_gemm_big_kernel), workgroup shape `cfg`; -1 when the shape does not fit.
@@ -1788,10 +1750,10 @@ static void frag_variant(hipStream_t st, bool lnf, const half_t* xf, const half_
   const dim3 grid(N / 16 / NT, ((R + 15) / 16 + RT - 1) / RT);
   if (lnf)
     dec_gemm_frag_kernel<WAVES, true, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, s1, cf, nullptr, 0, out, N,
-                                                                              nullptr, R, N, K, 0, PfArgs{nullptr, 0, 0, nullptr});
+                                                                              nullptr, R, N, K, 0);
   else
     dec_gemm_frag_kernel<WAVES, false, RT, NT, CH><<<grid, WAVES * 64, 0, st>>>(xf, Wf, bias, nullptr, nullptr, nullptr,
-                                                                               0, out, N, nullptr, R, N, K, 0, PfArgs{nullptr, 0, 0, nullptr});
+                                                                               0, out, N, nullptr, R, N, K, 0);
 }
 int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const half_t* xf, const half_t* Wf,
                                  const half_t* bias, const float* s1, const float* cf, half_t* out, int R, int N,
@@ -1823,7 +1785,6 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
 }
 
 static bool skinny_one_tile(int R, int N) { return R <= 16 || (R <= 96 && N <= 1280); }
-#define DEC_PF_MAX_ROWS 160   /* runs above it stream their weights for hundreds of rows: nothing to hide */
 
 // The per-layer decoder linears: K split over the waves of a workgroup, 2 x 2 tiles of 16 x 16 per workgroup
 // (measured best of {1,2} x {1,2}: profiles/r01_sweep_dec_gemm_frag_tiles.jsonl), row groups on grid.y so any
@@ -1831,33 +1792,22 @@ static bool skinny_one_tile(int R, int N) { return R <= 16 || (R <= 96 && N <= 1
 // (fragment-major, for the next GEMM) are both optional; res is row-major.
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                         int N, int K, int act, const NextLinear* next) {
+                         int N, int K, int act) {
   // Merged runs of >= DEC_BIG_MIN_ROWS rows: the LDS-staged GEMM-shaped kernel, 256 x 128 tiles for the wide linears and
   // 128 x 64 for those with 1280 columns (measured per layer at 1 520 rows: 216 -> 157 us; the register-streaming kernel
   // with 4 x 4 tiles reaches 174: profiles/r03_dec_linear_bench.txt).  Same K slices, same reduction order, same pinned
   // epilogue as the register-streaming kernel: the same bits.
   if (R >= DEC_BIG_MIN_ROWS && launch_dec_gemm_big(st, N >= 2560 ? 0 : 1, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
     return 0;
-  return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, next);
+  return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
 }
 
 int dec_big_min_rows() { return DEC_BIG_MIN_ROWS; }
 
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
-                           int N, int K, int act, const NextLinear* next) {
+                           int N, int K, int act) {
   if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
-  // the prefetch wave (solo-size runs): which bytes the NEXT linear of this run will read, and from which XCD — its
-  // register-streaming launch has grid.x = N' / 16 / NT' column groups of NT' * K'/32 KB, group j on XCD j % 8
-  PfArgs pfa = {nullptr, 0, 0, nullptr};
-  if (next && next->w && next->sink && R <= DEC_PF_MAX_ROWS && next->K % 32 == 0 && next->N % 32 == 0) {
-    const int nt2 = skinny_one_tile(R, next->N) ? 1 : 2;
-    const int groups = next->N / 16 / nt2;
-    const unsigned cg = (unsigned)nt2 * (unsigned)(next->K >> 5) * 1024u;
-    if ((groups & 7) == 0 && (cg & 4095u) == 0)
-      pfa = PfArgs{reinterpret_cast<const char*>(next->w), cg, groups, next->sink};
-  }
-  const PfArgs* pf = pfa.base ? &pfa : nullptr;
   const int waves = K >= 2560 ? 8 : 4;   // keeps a wave's share at <= 20 k-steps = 2 chunks of loads
   // Tile grouping by row count (the arithmetic of an output does not depend on it: same bits).  One 16 x 16 tile per
   // workgroup when there are few rows — twice to four times the workgroups streaming the weights, a wave's whole K share
@@ -1866,12 +1816,12 @@ int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, c
   // DEC_BIG_MIN_ROWS (4 x 2, 2 x 4, 4 x 4 tiles measured no better there: profiles/r03_dec_linear_bench.txt, README.md)
   const bool one_tile = skinny_one_tile(R, N);
   if (one_tile) {
-    if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
-    else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
+    if (s1) frag_go<true, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    else frag_go<false, 1, 1, 10>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     return 0;
   }
-  if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
-  else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act, pf);
+  if (s1) frag_go<true, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+  else frag_go<false, 2, 2>(st, waves, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
   return 0;
 }
 

@@ -84,7 +84,6 @@ struct GenWorkspace {
   float* cand_val = nullptr;             // [R][32]
   int* cand_tok = nullptr;
   int *done = nullptr, *n_done = nullptr, *n_fin = nullptr, *fin_tok = nullptr, *fin_len = nullptr;
-  int* pf_sink = nullptr;   // never written (dec_kernels.hip: PfArgs)
   float *fin_score = nullptr, *fin_cum = nullptr;
   int* d_step = nullptr;
   float* no_speech = nullptr;
@@ -259,7 +258,7 @@ static int gen_workspace_build(Model* m) {
   A(g->cand_val, R * 32);
   A(g->cand_tok, R * 32);
   // per-chunk state is sized by ROWS: random sampling runs every hypothesis as its own beam-1 chunk
-  A(g->done, R); A(g->n_done, 1); A(g->n_fin, R); A(g->pf_sink, 1);
+  A(g->done, R); A(g->n_done, 1); A(g->n_fin, R);
   A(g->fin_tok, R * FIN_CAP * NT); A(g->fin_len, R * FIN_CAP);
   A(g->fin_score, R * FIN_CAP); A(g->fin_cum, R * FIN_CAP);
   A(g->d_step, 1);
@@ -310,7 +309,7 @@ void gen_workspace_free(Model* m) {
   void* ptrs[] = {g->slot_map, g->sk, g->sv, g->x, g->qkv, g->att, g->qc, g->ffn, g->logits, g->prompt_dev,
                   g->cur_tok, g->hist2, g->cum2, g->kvidx2, g->cand_val, g->cand_tok, g->done, g->n_done, g->n_fin,
                   g->fin_tok, g->fin_len, g->fin_score, g->fin_cum, g->d_step, g->no_speech, g->sup_bits,
-                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag, g->xn_frag, g->pf_sink, g->prompt_blk};
+                  g->zero_done, g->xq, g->xs, g->ekq, g->eks, g->x_frag, g->att_frag, g->ffn_frag, g->xn_frag, g->prompt_blk};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -392,23 +391,6 @@ struct StepCfg {
     }                                                                   \
   } while (0)
 
-// Weight prefetch of solo runs (knob 3 / FWAMD_WPREFETCH, default ON): every register-streaming linear of a run of
-// <= 160 rows carries one extra wave per workgroup that touches the NEXT linear's weight tiles into the L2 of the XCD
-// that will read them (dec_kernels.hip: dec_gemm_frag_kernel<.., PF>).  Round 5 first tried it as a shadow branch of the
-// step graph (a prefetch kernel per linear on a second captured stream): 2.3x SLOWER — every fork edge of a HIP graph
-// costs ~10 us (profiles/r05_ab_wprefetch_shadow_branch.jsonl) — so the prefetch rides inside the producer's launch.
-static std::atomic<int> g_wprefetch{-1};
-bool wprefetch_on() {
-  int v = g_wprefetch.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("FWAMD_WPREFETCH");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-    g_wprefetch.store(v);
-  }
-  return v != 0;
-}
-void set_wprefetch(int on) { g_wprefetch.store(on ? 1 : 0); fwd::bump_kernel_forms_epoch(); }
-
 // position blocks for the prompt forward and align (knob 4 / FWAMD_POS_BLOCKS, default ON; 0: one position per pass,
 // rounds 1-4): the same bits either way (tests/test_gpu_model.py::test_position_blocks_same_bits)
 static std::atomic<int> g_pos_blocks{-1};
@@ -454,14 +436,10 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
   };
   // fp16: xin is the fragment-major copy of the input; the residual stream is kept row-major too (residual
   // adds), the FFN hidden only fragment-major; LayerNorms are folded into qkv / cross-q / ffn1
-  // nxt: the linear this run launches next — its weights are touched into L2 by an extra wave of THIS launch (solo-size
-  // runs only; knob 3)
-  const bool pf_on = wprefetch_on();
   auto lin_f = [&](const half_t* xin_frag, const LinearW& L, const half_t* res, half_t* outp, half_t* outp_frag,
-                   int act, const LinearW* nxt = nullptr) -> int {
-    const fwd::NextLinear nl = {nxt ? nxt->w : nullptr, nxt ? nxt->N : 0, nxt ? nxt->K : 0, g->pf_sink};
+                   int act) -> int {
     return fwd::launch_dec_gemm_frag(st, xin_frag, L.w, L.b, L.s1, L.cf, res, L.N, outp, L.N, outp_frag, rows, L.N,
-                                     L.K, act, (pf_on && nxt) ? &nl : nullptr);
+                                     L.K, act);
   };
   const int frag = i8 ? 0 : 1;
   // fp16, explicit-LayerNorm order (Model::ln_unfold == 2): the LayerNorm is its own kernel, its fp16 output (fragment-
@@ -483,7 +461,7 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
       ProfScope ps(m, PF_DEC_GEMM_QKV, 2.0 * rows * 3.0 * d * d, 2.0 * 3.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln1, L.qkv, nullptr, g->qkv, 0));
       else if (unf) DG(lin_u(L.ln1, L.qkv_p, g->qkv, nullptr, 0));
-      else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0, &L.out));
+      else DG(lin_f(g->x_frag, L.qkv, nullptr, g->qkv, nullptr, 0));
     }
     {
       ProfScope ps(m, PF_DEC_SELF_ATTN, 0, 0, st);
@@ -496,9 +474,9 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
         DG(lin_q(g->att, nullptr, L.out, g->x, g->x, 0));
         DG(lin_q(g->x, &L.ln2, L.cq, nullptr, g->qc, 0));
       } else {
-        DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0, unf ? nullptr : &L.cq));
+        DG(lin_f(g->att_frag, L.out, g->x, g->x, g->x_frag, 0));
         if (unf) DG(lin_u(L.ln2, L.cq_p, g->qc, nullptr, 0));
-        else DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0, &L.cout));
+        else DG(lin_f(g->x_frag, L.cq, nullptr, g->qc, nullptr, 0));
       }
     }
     if (s.probs && s.sel_layer_off[l + 1] > s.sel_layer_off[l]) {
@@ -515,19 +493,18 @@ static int run_step(Model* m, const GenDev& gp, const StepCfg& s) {
     {
       ProfScope ps(m, PF_DEC_GEMM_DXD, 2.0 * rows * 1.0 * d * d, 2.0 * 1.0 * d * d, st);
       if (i8) DG(lin_q(g->att, nullptr, L.cout, g->x, g->x, 0));
-      else DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0, unf ? nullptr : &L.ffn1));
+      else DG(lin_f(g->att_frag, L.cout, g->x, g->x, g->x_frag, 0));
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN1, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->x, &L.ln3, L.ffn1, nullptr, g->ffn, 1));
       else if (unf) DG(lin_u(L.ln3, L.ffn1_p, nullptr, g->ffn_frag, 1));
-      else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1, &L.ffn2));
+      else DG(lin_f(g->x_frag, L.ffn1, nullptr, nullptr, g->ffn_frag, 1));
     }
     {
       ProfScope ps(m, PF_DEC_GEMM_FFN2, 2.0 * rows * 4.0 * d * d, 2.0 * 4.0 * d * d, st);
       if (i8) DG(lin_q(g->ffn, nullptr, L.ffn2, g->x, g->x, 0));
-      else DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0,
-                    (!unf && l + 1 < c.n_dec_layers) ? &m->dec[l + 1].qkv : nullptr));
+      else DG(lin_f(g->ffn_frag, L.ffn2, g->x, g->x, g->x_frag, 0));
     }
   }
   if (s.need_logits || s.beam_tail) {

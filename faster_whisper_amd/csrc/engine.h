@@ -244,8 +244,6 @@ int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, ha
 int run_encoder(Model* m, int B, half_t* out);
 
 // decoder entry points (decoder.hip)
-void set_wprefetch(int on);                   // fw_test_knob(3, ..): the weight-prefetch wave of solo-size linears
-bool wprefetch_on();
 void set_pos_blocks(int on);                  // fw_test_knob(4, ..): position blocks for the prompt forward and align
 uint64_t next_tensor_id();
 int gen_workspace_ensure(Model* dm);          // creates dm's decode workspace on first use (caller holds dm->dec_mu)

@@ -1815,14 +1815,11 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
   }
   // use_int8 >= 10: the GEMM-shaped kernel of merged runs (dec_gemm_big_kernel), workgroup shape use_int8 - 10,
   // whatever the row count; 5: the skinny kernel whatever the row count (the reference of the bit-identity test).
-  // 0 (what a decode step launches) names a next linear as a step does — these same weights — so that solo-size row
-  // counts take the instantiation with the prefetch wave; 5 / 6 / 7 take the one without: the same bits
-  const fwd::NextLinear nl = {d_wf, N, K, reinterpret_cast<int*>(d_of)};   // (the sink is never written)
   const int lr =
       use_int8 >= 10 ? fwd::launch_dec_gemm_big(st, use_int8 - 10, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
       : use_int8 == 5 ? fwd::launch_dec_gemm_skinny(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
       : (use_int8 == 6 || use_int8 == 7) ? fwd::launch_dec_gemm_skinny_tiles(st, use_int8 - 5, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act)
-                      : fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act, &nl);
+                      : fwd::launch_dec_gemm_frag(st, d_xf, d_wf, d_bias, d_s1, d_cf, d_res, N, d_out, N, d_of, R, N, K, act);
   if (lr != 0) {
     cleanup();
     set_error("decoder linear: unsupported shape R=%d N=%d K=%d", R, N, K);
@@ -1842,10 +1839,9 @@ int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {
-  FW_CHECK_ARG(id >= 1 && id <= 4, "unknown knob %d", id);
+  FW_CHECK_ARG(id == 1 || id == 2 || id == 4, "unknown knob %d", id);
   if (id == 1) fwk::g_gemm_order.store(value);
   else if (id == 2) fwd::set_self_attn_form(value);
-  else if (id == 3) set_wprefetch(value);
   else set_pos_blocks(value);
   return FW_OK;
 }

@@ -59,8 +59,8 @@ int32_t fw_bench_attention(fw_model* m, int32_t B, int32_t H, int32_t T, int32_t
 int32_t fw_dec_big_min_rows(void);
 /* process-wide measurement knob for A/B runs inside one process.  id 1: encoder GEMM tile order (1 = blocked, the
  * product's; 0 = n fastest across the whole width, rounds 1-3).  id 2: decoder self-attention form (0 = by launch size,
- * the product's; 1 = the first form of rounds 1-4; 2 = latency form; 3 = throughput form — all four return the same bits).  id 3: the weight-prefetch wave of solo-size decoder linears
- * (0 / 1; default 1, FWAMD_WPREFETCH=0 turns it off).  id 4: position blocks for the prompt forward and align (1, the default:
+ * the product's; 1 = the first form of rounds 1-4; 2 = latency form; 3 = throughput form — all four return the same bits).  id 4 (3 was the weight prefetch of
+ * solo runs, measured slower twice and removed: profiles/r05_ab_wprefetch_*.jsonl): position blocks for the prompt forward and align (1, the default:
  * up to 16 positions per decoder pass; 0: one position per pass, rounds 1-4 — the same bits) */
 int32_t fw_test_knob(int32_t id, int32_t value);
 

@@ -404,34 +404,6 @@ def test_self_attention_forms_return_the_same_bits(setup):
     print(f"[{cfg.name}] self-attention forms 1 / 2 / 3 / auto: identical ids, scores and no-speech bits over 3 configurations")
 
 
-def test_weight_prefetch_wave_same_results(setup):
-    """Round 5 (fw_test_knob 3 / FWAMD_WPREFETCH, default on): every register-streaming decoder linear of a solo-size run
-    carries one extra wave per workgroup that touches the NEXT linear's weight tiles into L2 (dec_gemm_frag_kernel<.., PF>).
-    The wave computes nothing and takes no barrier: results must not move by a bit, eagerly and as a replayed graph."""
-    from faster_whisper_amd import _lib
-    from faster_whisper_amd.backend import StorageView
-    cfg, model, oracle, feats = setup
-    lib = _lib.load()
-    enc = model.encode(StorageView.from_array(feats))
-    res = {}
-    try:
-        for on in (0, 1, 0):
-            _lib.check(lib.fw_test_knob(3, on))
-            outs = []
-            for beam, ts in ((5, True), (1, False)):
-                prompt = _prompt(cfg, ts)
-                kw = dict(beam_size=beam, max_length=len(prompt) + 30, suppress_blank=True, suppress_tokens=_suppress(cfg),
-                          max_initial_timestamp_index=50)
-                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
-                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)   # the replay
-                outs.append([(g.sequences_ids, g.scores, g.no_speech_prob) for g in got])
-            res.setdefault(on, []).append(outs)
-    finally:
-        _lib.check(lib.fw_test_knob(3, 1))
-    assert res[1][0] == res[0][0] == res[0][1]
-    print(f"[{cfg.name}] weight-prefetch wave on / off: identical results")
-
-
 def test_position_blocks_same_bits(setup):
     """Round 5 (fw_test_knob 4, default on): the prompt forward of `generate` and the teacher-forced pass of `align` go
     through the decoder in blocks of up to 16 positions per pass (rows = chunks x positions; a sibling position's K / V
