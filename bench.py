@@ -234,6 +234,10 @@ def parse_args(argv=None):
                     help="skip the secondary measurements (pipeline, cap_case, single_utterance, sharded_recording)")
     ap.add_argument("--pipeline-chunks", type=int, default=960,
                     help="30 s chunks of the end-to-end recording (960 = 8 h: >= 10 s of wall, a steady state)")
+    ap.add_argument("--dry-dist", action="store_true",
+                    help="N > 1 only: initialise the process group, broadcast the weight blob, build the model, decode ONE "
+                         "batch per rank, gather once, and print the seconds every phase took on every rank — so that a "
+                         "failing multi-GPU lease says WHERE (rendezvous, RCCL, blob, HBM pools, first launch)")
     ap.add_argument("--sharded-chunks", type=int, default=120,
                     help="30 s chunks of the recording sharded over the ranks at N > 1 (BASELINE config C4: 1 h)")
     return ap.parse_args(argv)
@@ -260,6 +264,17 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     dist = None
     on_gpu = dist_backend in (None, "nccl")
     multi = _multi(world)
+    phases = {}          # seconds per start-up phase of THIS rank (--dry-dist prints them; stderr gets them as they pass)
+    t_ph = time.time()
+
+    def phase(name):
+        nonlocal t_ph
+        now = time.time()
+        phases[name] = round(now - t_ph, 3)
+        t_ph = now
+        if multi:
+            print(f"[bench rank {rank}/{world}] {name}: {phases[name]:.2f} s", file=sys.stderr, flush=True)
+
     if multi:
         import torch
         import torch.distributed as dist
@@ -268,9 +283,13 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         if on_gpu:
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
+        phase("import_torch")
         # a rank that fails before a collective must not leave the others waiting for ever
         dist.init_process_group(dist_backend or "nccl", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=300), **kw)
+        phase("init_process_group")
+        dist.barrier()                 # the first collective creates the communicator (RCCL: rings over xGMI)
+        phase("first_barrier")
 
     from faster_whisper_amd import get_config
     from faster_whisper_amd.sharding import gather_results
@@ -279,12 +298,19 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     t0 = time.time()
     model, weights = (backend_factory or build_backend)(args, cfg, rank, world, local_rank)
     load_s = time.time() - t0
+    phase("blob_broadcast_and_model")
 
     lanes = getattr(args, "decode_lanes", 2)
     if lanes != 2 and hasattr(model, "set_decode_lanes"):
         model.set_decode_lanes(lanes)
     chunks = synth_chunks(args.batch, seed=1000 + rank)
     staged = model.stage_pcm(chunks)
+    # every worker slot of the pool its OWN 16 chunks of PCM (resident in HBM like `staged`): the batches in flight are
+    # different audio, as the batches of a recording are (step i takes set i mod W; set 0 = `staged`)
+    staged_sets = [staged]
+    if hasattr(model, "stage_pcm") and not getattr(args, "dry_dist", False):
+        for w in range(1, max(1, args.workers)):
+            staged_sets.append(model.stage_pcm(synth_chunks(args.batch, seed=1000 + rank + 7919 * w)))
     prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
     L = args.new_tokens
     sup = [cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe]
@@ -294,8 +320,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                     return_scores=True, return_no_speech_prob=True, suppress_blank=True, suppress_tokens=sup,
                     min_new_tokens=n)
 
-    def step(n=L):
-        enc = model.encode_pcm_staged(staged)
+    def step(n=L, which=0):
+        enc = model.encode_pcm_staged(staged_sets[which % len(staged_sets)])
         return model.generate(enc, [prompt] * args.batch, **gen_kw(n))
 
     def barrier():
@@ -318,7 +344,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         return r
 
     def run_steps(n, n_tok=L, gather=True):
-        futs = [pool.submit(step, n_tok) for _ in range(n)]
+        futs = [pool.submit(step, n_tok, i) for i in range(n)]
         outs = [f.result() for f in futs]          # results come back in submission order = chunk order
         if multi and gather:
             # ONE gather per timed region (the path has no collective inside it: DESIGN.md section 7): the fixed-size
@@ -335,6 +361,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         barrier()
         dt = time.perf_counter() - t1
         last["res"] = res
+        last["which"] = n - 1            # the PCM set of the last step (run_steps: step i takes set i mod W)
         if multi:
             import torch
             tt = torch.tensor([dt], device=f"cuda:{local_rank}" if on_gpu else "cpu")
@@ -343,8 +370,29 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         assert all(len(r.sequences_ids[0]) == n_tok for r in res), "decode length is not the requested fixed length"
         return dt
 
+    if getattr(args, "dry_dist", False):
+        if not multi:
+            raise SystemExit("bench.py: --dry-dist is the N > 1 start-up check (use --gpus N)")
+        phase("stage_pcm")
+        res = step()
+        model.synchronize()
+        phase("first_batch")
+        gather_results(res, L, rank, world, local_rank)
+        phase("gather")
+        allp = [None] * world
+        dist.all_gather_object(allp, phases)
+        if rank == 0:
+            print(json.dumps({"dry_dist": True, "n_gpus": world, "phases_s_by_rank": allp,
+                              "slowest_phase": max(((k, max(p.get(k, 0.0) for p in allp)) for k in phases),
+                                                   key=lambda kv: kv[1])}), flush=True)
+        model.free_staged(staged)
+        pool.shutdown()
+        dist.barrier()
+        dist.destroy_process_group()
+        return {"dry_dist": True}
     if args.warmup > 0:
         list(pool.map(warm, range(W)))
+    phase("warmup")
     stats0 = model.decode_stats()
     elapsed = timed(args.steps)
     stats1 = model.decode_stats()
@@ -353,7 +401,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     #      must be identical bit for bit (every kernel works per row / per chunk; tests/test_gpu_full_size.py checks
     #      the same geometry against the oracle) ----
     merged_res = last["res"]
-    solo_res = step()
+    solo_res = step(which=last["which"])
     verified = all(a.sequences_ids == b.sequences_ids and a.scores == b.scores and a.no_speech_prob == b.no_speech_prob
                    for a, b in zip(merged_res, solo_res)) and len(merged_res) == len(solo_res) == args.batch
 
@@ -391,7 +439,15 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     ceiling = {100: 4525.0, 224: 2211.0}
     if args.model == "large-v3" and args.compute_type == "float16" and L in ceiling:
         out["roofline_combined"] = {"value_over_ceiling": round(value / (ceiling[L] * world), 4),
-                                    "ceiling_per_gpu": ceiling[L], "source": "SURVEY.md section 8d"}
+                                    "ceiling_per_gpu": ceiling[L], "source": "SURVEY.md section 8d",
+                                    "attainable_note": "SURVEY's ceiling charges the 1.47 GB of decoder weights to every "
+                                                       "16-chunk batch and step; merged decode runs stream them once per RUN "
+                                                       "(~16 batches).  With that, per batch: cross-attention 393 GB at the "
+                                                       "6.3 TB/s a copy achieves = 64.3 ms, weights 1.5 ms, encoder + cross-K/V "
+                                                       "+ decoder linears 53 TFLOP at the 2.5 PFLOP/s MFMA peak = 21.2 ms: "
+                                                       "5 500x with the two roofs ADDED (SURVEY's method), 7 450x if they "
+                                                       "overlapped perfectly — the fraction over 4 525x flatters the gap"}
+        out["roofline_combined"]["value_over_merged_run_ceiling"] = round(value / (5500.0 * world), 4)
     secondary = not args.no_secondary
     # ---- secondary, all ranks take part: steady state, the cap case and (N > 1) the sharded recording ----
     if secondary and args.steps < 2 * W:
@@ -477,7 +533,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                     others[k] = rep[k]
             out["roofline_others"] = {
                 k: dict(roof_of(k, v), kernel_ms_per_step=round(v["ms"], 3),
-                        traffic=(pmc_traffic(k) or {}).get("hbm_read_bytes_per_launch"))
+                        traffic=(pmc_traffic(k, gemm_shaped) or {}).get("hbm_read_bytes_per_launch"),
+                        traffic_kernel=(pmc_traffic(k, gemm_shaped) or {}).get("kernel"))
                 for k, v in others.items()
                 if v["ms"] > 0 and (v["flops"] > 0 if (k in MFMA_FAMILIES or (k == "dec_gemm" and gemm_shaped))
                                     else v["bytes"] > 0)}
@@ -509,7 +566,8 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks[0], prompt, args.beam, L, gen_kw(L))
         print(json.dumps(out), flush=True)
-    model.free_staged(staged)
+    for st_ in staged_sets:
+        model.free_staged(st_)
     pool.shutdown()
     if multi:
         dist.barrier()
@@ -569,59 +627,59 @@ def one_batch(model, staged, chunks, prompt, kw, L, batch, reps=4):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-PMC_FETCH_FILE = "r04_pmc_fetch.json"     # the round's counter passes (profiles/collect.sh r04): one batch per decode
-PMC_FETCH_MERGED_FILE = "r04_pmc_fetch_w32.json"   # run, and the timed configuration (32 workers, merged runs)
+PMC_TAGS = ("r05", "r04")                 # the round's counter passes (profiles/collect.sh <tag>), newest first:
+#   <tag>_pmc_fetch_w32.json   the TIMED configuration (32 workers, merged decode runs, one lane)
+#   <tag>_pmc_fetch.json       one 16-chunk batch per decode run
 _PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "gemm_f16", "enc_attn": "attn_enc_kernel",
-               "dec_gemm": "dec_gemm_frag_kernel", "dec_self_attn": "dec_self_attn_kernel",
-               "dec_logits": "dec_gemm_wave_kernel"}
+               "dec_gemm": "dec_gemm_frag_kernel", "dec_self_attn": "dec_self_attn", "dec_logits": "dec_gemm_wave_kernel"}
 
 
-def pmc_traffic(family):
-    """HBM read bytes per launch of the family's kernel from the newest committed rocprofv3 --pmc FETCH_SIZE pass
-    (profiles/rNN_pmc_fetch*.json, x2 gfx950 correction already applied by profiles/parse_pmc.py); null if that
-    kernel was not measured."""
-    import glob
+def _pmc_file(suffix):
+    for tag in PMC_TAGS:
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_{suffix}.json")
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def pmc_traffic(family, gemm_shaped=False):
+    """HBM read bytes per launch of the family's kernel from the newest committed rocprofv3 --pmc FETCH_SIZE pass of the
+    TIMED configuration (merged decode runs; the one-batch-per-run pass when that kernel is not in it), x2 gfx950
+    correction already applied by profiles/parse_pmc.py; null if the kernel was not measured.  gemm_shaped: the decoder
+    linears of the profiled round took dec_gemm_big_kernel (runs >= fw_dec_big_min_rows rows) — its figure, not the
+    register-streaming kernel's."""
     if family not in _PMC_KERNEL:
         return None
-    merged = os.path.join(ROOT, "profiles", PMC_FETCH_MERGED_FILE)
-    if family == "dec_cross_attn" and os.path.exists(merged):
-        # the dominant kernel: FETCH_SIZE from the pass that ran the TIMED configuration (merged decode runs); the launch's
-        # grid gives the chunks it streamed, hence its algorithmic bytes (profiles/parse_pmc.py)
-        with open(merged) as f:
+    kernel = "dec_gemm_big_kernel" if (family == "dec_gemm" and gemm_shaped) else _PMC_KERNEL[family]
+    for suffix, what in (("fetch_w32", "the counter pass of the timed configuration (profiles/collect.sh: the bench command "
+                                       "with 32 workers, one decode lane, eager decode step: merged decode runs)"),
+                         ("fetch", "the counter pass with --workers 1 (one 16-chunk batch per decode run, eager decode step)")):
+        path = _pmc_file(suffix)
+        if not path:
+            continue
+        with open(path) as f:
             j = json.load(f)
-        for k, v in j.items():
-            if _PMC_KERNEL[family] in k and v.get("algorithmic_bytes_per_launch"):
-                return {"hbm_read_bytes_per_launch": round(v["hbm_read_bytes_per_launch_corrected"]),
-                        "algorithmic_bytes_per_launch_in_that_pass": round(v["algorithmic_bytes_per_launch"]),
-                        "chunks_per_launch_in_that_pass": round(v["chunks_per_launch_mean"], 1),
-                        "source": os.path.relpath(merged, ROOT),
-                        "note": "mean over the launches of that kernel in the counter pass of the timed configuration "
-                                "(profiles/collect.sh: the bench command with 32 workers, one decode lane, eager decode "
-                                "step: merged decode runs)"}
-    files = [os.path.join(ROOT, "profiles", PMC_FETCH_FILE)]
-    if not os.path.exists(files[0]):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch.json")))
-    if not files:
-        return None
-    path = files[-1]
-    with open(path) as f:
-        j = json.load(f)
-    tot = n = 0.0
-    for k, v in j.items():            # a templated kernel appears once per instantiation: dispatch-weighted mean
-        b = v.get("hbm_read_bytes_per_launch_corrected")
-        if _PMC_KERNEL[family] in k and b is not None:
-            d = v.get("FETCH_SIZE", {}).get("dispatches", 1)
-            tot += b * d
-            n += d
-    if n == 0:
-        return None
-    out = {"hbm_read_bytes_per_launch": round(tot / n), "source": os.path.relpath(path, ROOT),
-           "note": "mean over the launches of that kernel in the counter pass (profiles/collect.sh: the same bench "
-                   "command with --workers 1, i.e. one 16-chunk batch per decode run, eager decode step)"}
-    if family == "dec_cross_attn":
-        # one launch = one decoder layer for the chunks of the run: K and V^T of that layer, 1500 x 1280 fp16 each
-        out["algorithmic_bytes_per_launch_in_that_pass"] = 16 * 2 * 1500 * 1280 * 2
-    return out
+        tot = n = alg = chunks = 0.0
+        for k, v in j.items():            # a templated kernel appears once per instantiation: dispatch-weighted mean
+            b = v.get("hbm_read_bytes_per_launch_corrected")
+            if kernel in k and b is not None:
+                d = v.get("FETCH_SIZE", {}).get("dispatches", 1)
+                tot += b * d
+                n += d
+                alg += v.get("algorithmic_bytes_per_launch", 0.0) * d
+                chunks += v.get("chunks_per_launch_mean", 0.0) * d
+        if n == 0:
+            continue
+        out = {"hbm_read_bytes_per_launch": round(tot / n), "kernel": kernel, "source": os.path.relpath(path, ROOT),
+               "note": "mean over the launches of that kernel in " + what}
+        if family == "dec_cross_attn":
+            # one launch = one decoder layer for the chunks of the run: K and V^T of that layer, 1500 x 1280 fp16 each;
+            # merged runs: the launch's grid gives the chunks it streamed (profiles/parse_pmc.py)
+            out["algorithmic_bytes_per_launch_in_that_pass"] = round(alg / n) if alg else 16 * 2 * 1500 * 1280 * 2
+            if chunks:
+                out["chunks_per_launch_in_that_pass"] = round(chunks / n, 1)
+        return out
+    return None
 
 
 def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):

@@ -1671,7 +1671,7 @@ namespace fwd {
 
 // row count from which the decoder linears of a decode run take the LDS-staged GEMM-shaped kernel
 // (profiles/r03_dec_linear_bench.txt)
-#define DEC_BIG_MIN_ROWS 1024
+#define DEC_BIG_MIN_ROWS 704   /* the lowest of the per-linear crossovers (launch_dec_gemm_frag) */
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d, const int* d_step, int pos_fixed, int P, int blk_n) {
@@ -1797,7 +1797,20 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
   // 128 x 64 for those with 1280 columns (measured per layer at 1 520 rows: 216 -> 157 us; the register-streaming kernel
   // with 4 x 4 tiles reaches 174: profiles/r03_dec_linear_bench.txt).  Same K slices, same reduction order, same pinned
   // epilogue as the register-streaming kernel: the same bits.
-  if (R >= DEC_BIG_MIN_ROWS && launch_dec_gemm_big(st, N >= 2560 ? 0 : 1, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
+  // Round 5: the crossover is per linear (profiles/r05_dec_linear_bench_call1.txt, us per launch, register-streaming vs
+  // LDS-staged at 800 / 960 / 1 120 rows): qkv 27.3 / 31.8 / 36.1 vs 25.0 / 25.8 / 35.3 (128 x 128 tiles; 256 x 128 from
+  // 1 280 rows), ffn1 34.4 / 40.0 / 45.0 vs 34.9 / 35.3 / 37.3 (256 x 128), ffn2 33.0 / 39.1 / 45.1 vs 35.8 / 35.9 / 36.6
+  // (128 x 64), d x d 10.1 / 11.9 / 13.2 vs 12.8 / 13.0 / 13.1 (128 x 64): the fixed ~12-35 us of an LDS-staged launch
+  // (its K loop's latency) is reached at a different row count by each shape.  Same bits from every form.
+  int cfg = -1;
+  if (N >= 2560) {
+    if (N == 3 * K) cfg = R >= 1280 ? 0 : (R >= 704 ? 2 : -1);                       // qkv (N = 3 d)
+    else cfg = R >= 864 ? 0 : -1;                                                    // ffn1 (N = 4 d)
+  } else {
+    cfg = (K >= 2560 ? R >= 896 : R >= 1120) ? 1 : -1;                               // ffn2 (K = 4 d) / d x d
+  }
+  if (cfg >= 0 && R >= DEC_BIG_MIN_ROWS &&
+      launch_dec_gemm_big(st, cfg, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
     return 0;
   return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
 }
@@ -1848,7 +1861,7 @@ int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_sca
                             const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
                             int R, int N, int K, int act) {
   if (K % 64 != 0 || N % 32 != 0 || R < 1 || !x_scale || !w_scale) return -1;
-  if (R >= DEC_BIG_MIN_ROWS && N % 64 == 0) {
+  if (R >= 1024 && N % 64 == 0) {   // (measured crossover of the int8 forms)
     // merged runs: 4 x 4 tiles per workgroup, a quarter of the operand traffic per output (the fp16 form of this grouping
     // measured 216 -> 174 us per layer at 1 520 rows); integer accumulation: the result does not depend on the grouping
     const dim3 g4(N / 64, ((R + 15) / 16 + 3) / 4);

@@ -776,7 +776,9 @@ static int generate_run(Model* m, const std::vector<GenRequest*>& reqs) {
           hipGraphExec_t ne = nullptr;
           if (rc2 == FW_OK && e2 == hipSuccess && graph && hipGraphInstantiate(&ne, graph, nullptr, nullptr, 0) == hipSuccess) {
             GraphSlot* slot = nullptr;
-            if (g->graphs.size() < 12) { g->graphs.emplace_back(); slot = &g->graphs.back(); }
+            // (merged runs come in every multiple of a batch up to the lane's capacity: 20 sizes with the bench's workers;
+            //  a cache of 12 re-captured and re-instantiated 261-node graphs all the time)
+            if (g->graphs.size() < 40) { g->graphs.emplace_back(); slot = &g->graphs.back(); }
             else {   // evict the least recently used
               slot = &g->graphs[0];
               for (GraphSlot& gs : g->graphs) if (gs.stamp < slot->stamp) slot = &gs;

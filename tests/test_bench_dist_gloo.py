@@ -105,16 +105,18 @@ import os, sys
 sys.path.insert(0, os.environ["FW_ROOT"])
 import bench
 ''' + SEAM + r'''
-out = bench.main(["--gpus", os.environ["WORLD_SIZE"], "--model", "micro", "--batch", "4", "--beam", "5", "--steps", "6",
-                  "--warmup", "1", "--workers", "2", "--new-tokens", "12", "--pipeline-chunks", "11", "--sharded-chunks", "11",
-                  "--no-cpu-baseline"], backend_factory=factory, dist_backend="gloo")
+n_shard, batch = os.environ.get("FW_SHARDED_CHUNKS", "11"), os.environ.get("FW_BATCH", "4")
+out = bench.main(["--gpus", os.environ["WORLD_SIZE"], "--model", "micro", "--batch", batch, "--beam", "5",
+                  "--steps", os.environ.get("FW_STEPS", "6"),
+                  "--warmup", "1", "--workers", "2", "--new-tokens", "12", "--pipeline-chunks", "11", "--sharded-chunks", n_shard,
+                  "--no-cpu-baseline"] + os.environ.get("FW_EXTRA_ARGS", "").split(), backend_factory=factory, dist_backend="gloo")
 if int(os.environ["RANK"]) != 0:
     print("RANK_DONE", flush=True)
 if os.environ.get("FW_SERIAL_DIGEST"):
     # the same recording through the unsharded pipeline on a fresh scripted backend (no process group any more)
     from faster_whisper_amd import get_config
     cfg = get_config("micro")
-    serial = bench.pipeline_rtf(FakeBackend(cfg, 2, None), cfg, 11, 4, 5, 12, shard=False)
+    serial = bench.pipeline_rtf(FakeBackend(cfg, 2, None), cfg, int(n_shard), int(batch), 5, 12, shard=False)
     print("SERIAL " + json.dumps(serial), flush=True)
 '''
 
@@ -210,3 +212,61 @@ def test_bench_refuses_a_world_that_is_not_gpus(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "refusing" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def _run_ranks(tmp_path, world, extra_env, timeout=280):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FW_ROOT=ROOT, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", **extra_env)
+        env.pop("FWAMD_DIST_AT_WORLD_1", None)
+        if rank == 0 and "FW_EXTRA_ARGS" not in extra_env:
+            env["FW_SERIAL_DIGEST"] = "1"
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    return outs
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n_chunks", [120, 121])
+def test_bench_eight_ranks_one_hour_recording(tmp_path, n_chunks):
+    """BASELINE config C4 as the driver's 8-GPU run shapes it: EIGHT ranks, a 1 h recording = 120 chunks = one 15-chunk
+    batch per rank (and 121: an uneven block partition, rank 0 one chunk more), batches of 16.  Eight real processes over
+    gloo with the scripted backend: rendezvous, blob broadcast to 8 ranks, one gather of 8 x 2 steps, the MAX over ranks,
+    the sharded recording assembled on rank 0 — whose digest must be the unsharded pipeline's."""
+    outs = _run_ranks(tmp_path, 8, {"FW_SHARDED_CHUNKS": str(n_chunks), "FW_BATCH": "16", "FW_STEPS": "2"}, timeout=560)
+    for r in range(1, 8):
+        assert "RANK_DONE" in outs[r][0]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][0]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["config"]["global_batch"] == 128 and j["value"] > 0
+    sh = j["sharded_recording"]
+    assert "error" not in sh, sh
+    assert sh["segments"] == n_chunks and sh["n_gpus"] == 8 and sh["tokens"] == n_chunks * 12
+    serial = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("SERIAL ")][0][7:])
+    assert "error" not in serial and sh["digest"] == serial["digest"], (sh, serial)
+    # every rank reported its start-up phases on stderr (what a failing lease is read from)
+    for r in range(8):
+        assert f"[bench rank {r}/8] init_process_group" in outs[r][1] and "blob_broadcast_and_model" in outs[r][1]
+
+
+@pytest.mark.timeout(300)
+def test_bench_dry_dist(tmp_path):
+    """`bench.py --gpus N --dry-dist`: rendezvous -> blob broadcast -> model -> one batch per rank -> one gather -> exit;
+    rank 0 prints the seconds of every phase on every rank (the first thing to run on a fresh multi-GPU lease)"""
+    outs = _run_ranks(tmp_path, 2, {"FW_EXTRA_ARGS": "--dry-dist"})
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][0]
+    j = json.loads(lines[0])
+    assert j["dry_dist"] is True and j["n_gpus"] == 2 and len(j["phases_s_by_rank"]) == 2
+    for ph in j["phases_s_by_rank"]:
+        for k in ("init_process_group", "first_barrier", "blob_broadcast_and_model", "first_batch", "gather"):
+            assert k in ph, (k, ph)
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]

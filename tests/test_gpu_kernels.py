@@ -282,7 +282,7 @@ def test_gemm_cross_kv_fragment_major(model, M, N, K, vt):
 BIG_CFGS = (0, 1, 2)     # workgroup shapes of dec_gemm_big_kernel (dec_kernels.hip: launch_dec_gemm_big)
 
 
-@pytest.mark.parametrize("R", [5, 80, 333, 1521, 1680])
+@pytest.mark.parametrize("R", [5, 80, 333, 800, 960, 1521, 1680])
 def test_dec_linear_big_bit_identical(model, R):
     """the GEMM-shaped decoder linear of merged runs (dec_gemm_big_kernel: 64 x 64 outputs per wave, fragments staged
     once per workgroup tile in LDS) must return EXACTLY the bits of the skinny kernel of solo runs at every large-v3

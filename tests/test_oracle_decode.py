@@ -142,3 +142,37 @@ def test_topk_median_dtw_helpers():
     ti, fi = _dtw(np.array([[-1.0, -1.0, 0.0, 0.0], [0.0, 0.0, -1.0, -1.0]]))
     # (ties in the recurrence fall through to the "left" move, exactly like openai's dtw_cpu)
     assert ti.tolist() == [0, 0, 1, 1, 1] and fi.tolist() == [0, 1, 1, 2, 3]
+
+
+def test_fully_forced_call_in_one_pass_equals_step_by_step():
+    """OracleWhisper scores a GIVEN sequence (conftest.forced_result: every step forced) with ONE decoder_full pass over
+    prompt + tokens instead of one decoder_step per token (a 224-step large-v3 score sweeps the weights once, not 224
+    times).  Same layers, same rules, applied step by step to the precomputed logits.  In fp32 arithmetic the two paths
+    agree to summation order (1e-5); with fp16 emulation a last-bit difference of a matmul can move an fp16 rounding, which
+    is the evaluation-order noise the GPU tolerances already carry (bounded here at 2e-4 per token)."""
+    from faster_whisper_amd import get_config, synthetic_weights
+    from oracle.whisper import OracleWhisper
+    from conftest import forced_result
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=3)
+    enc = (np.random.default_rng(0).standard_normal((1500, cfg.d_model)) * 0.5).astype(np.float32)
+    for mode, per_tok in ((dict(emulate_fp16=False), 1e-6), (dict(emulate_fp16=True), 2e-4)):
+        o = OracleWhisper(cfg, w, **mode)
+        for ts in (False, True):
+            prompt = list(cfg.sot_sequence) + ([] if ts else [cfg.no_timestamps])
+            kw = dict(max_length=len(prompt) + 20, suppress_blank=True, length_penalty=1.0, max_initial_timestamp_index=50)
+            ids = o.generate(enc[None], [prompt], beam_size=1, **kw)[0].sequences_ids[0]
+            for seq in (ids, ids[:7]):            # the whole budget; a shorter one (ends with <eot>)
+                res = {}
+                for bf in (False, True):
+                    o.batch_forced = bf
+                    res[bf] = forced_result(o, enc, prompt, seq, dict(kw, beam_size=1))
+                a, b = res[False], res[True]
+                n = len(seq) + (1 if len(seq) < 20 else 0)
+                assert a.sequences_ids == b.sequences_ids
+                assert abs(a.scores[0] - b.scores[0]) / n < per_tok, (mode, ts, a.scores, b.scores)
+                assert abs(a.no_speech_prob - b.no_speech_prob) < 1e-7
+                assert len(a.forced_gaps) == len(b.forced_gaps) == n and len(a.margins) == len(b.margins)
+                if not mode["emulate_fp16"]:
+                    assert max(abs(x - y) for x, y in zip(a.margins, b.margins)) < 1e-4
+                    assert max(abs(x - y) for x, y in zip(a.forced_gaps, b.forced_gaps)) < 1e-4
