@@ -226,6 +226,11 @@ struct ProfScope {
 void prof_collect(Model* m);
 
 int dev_alloc(void** p, size_t bytes);
+// a non-blocking stream at the priority the environment variable `env` names ("high" / "low"; anything else, or unset:
+// the default priority).  ROCm gives every priority level its own hardware queues, so a decode stream created "high"
+// neither shares a hardware queue with the encoder streams of the workers nor waits behind their workgroups when a CU
+// frees up.  Measurement knob: FWAMD_DEC_STREAM_PRIO (decode lanes), FWAMD_ENC_STREAM_PRIO (encoder / replica streams).
+hipError_t create_stream(hipStream_t* st, const char* env);
 template <typename T>
 inline int dev_alloc_t(T** p, size_t n) { return dev_alloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
 

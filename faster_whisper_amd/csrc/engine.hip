@@ -720,7 +720,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
     m->tensors[e.name] = t;
   }
   auto fail = [&](int code) { fw_model_free(fm); return code; };
-  hipError_t he = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  hipError_t he = create_stream(&m->stream, decoder_lane ? "FWAMD_DEC_STREAM_PRIO" : "FWAMD_ENC_STREAM_PRIO");
   if (he != hipSuccess) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
     return fail(FW_ENODEV);
@@ -758,6 +758,16 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   m->self = fm;
   *out = fm;
   return FW_OK;
+}
+
+hipError_t create_stream(hipStream_t* st, const char* env) {
+  const char* e = env ? getenv(env) : nullptr;
+  if (e && (!strcmp(e, "high") || !strcmp(e, "low"))) {
+    int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      return hipStreamCreateWithPriority(st, hipStreamNonBlocking, e[0] == 'h' ? greatest : least);
+  }
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
 // ---------------------------------------------------------------- layers
