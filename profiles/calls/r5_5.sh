@@ -28,7 +28,6 @@ run base1 FWAMD_NOP=1
 run dec_high FWAMD_DEC_STREAM_PRIO=high
 run dec_high_enc_low FWAMD_DEC_STREAM_PRIO=high FWAMD_ENC_STREAM_PRIO=low
 run enc_low FWAMD_ENC_STREAM_PRIO=low
-run enc_high FWAMD_ENC_STREAM_PRIO=high
 run base2 FWAMD_NOP=1
 run dec_high2 FWAMD_DEC_STREAM_PRIO=high
 # the driver's command (20-step burst) with and without
