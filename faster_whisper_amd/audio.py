@@ -72,11 +72,26 @@ def _read_flac(data: bytes) -> Tuple[np.ndarray, int]:
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     rate, ch, bps, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     _lib.check(lib.fw_flac_info(buf, len(data), C.byref(rate), C.byref(ch), C.byref(bps), C.byref(total)))
-    # an unknown length (streamed encode) is bounded by the data: a sample costs at least one bit per channel
-    cap = total.value if total.value > 0 else 8 * len(data)
-    out = np.zeros((cap, ch.value), dtype=np.int32)
+    # Output sizing.  STREAMINFO's total is untrusted input (36 bits) and 0 for a streamed encode, and there is no useful
+    # lower bound on bytes per sample (a CONSTANT subframe codes a whole block of up to 65 535 samples in a few bytes):
+    # start from what the data plausibly holds and grow on "too small" up to the format's own ceiling for this many
+    # bytes (a frame is at least 11 bytes: header, one subframe byte per channel, CRC-16).
+    hard_cap = (len(data) // 11 + 1) * 65535
+    want = min(total.value, hard_cap) if total.value > 0 else hard_cap
+    cap = max(1, min(want, 16 * len(data)))
     n, md5 = C.c_int64(), C.c_int32()
-    _lib.check(lib.fw_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(md5)))
+    while True:
+        out = np.zeros((cap, ch.value), dtype=np.int32)
+        rc = lib.fw_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(md5))
+        if rc != 0 and cap < want and b"too small" in (lib.fw_last_error() or b""):
+            cap = min(want, cap * 4)
+            continue
+        _lib.check(rc)
+        break
+    if 0 < total.value != n.value:
+        import warnings
+        warnings.warn(f"FLAC: {n.value} of the {total.value} samples STREAMINFO announces were decoded "
+                      "(truncated stream or lost frame sync)", RuntimeWarning)
     if md5.value == 0:
         raise ValueError("FLAC: the decoded audio does not carry the MD5 signature stored in the stream (corrupt file)")
     x = (out[:n.value].astype(np.float64) / float(1 << (bps.value - 1))).astype(np.float32)

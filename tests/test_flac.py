@@ -298,3 +298,25 @@ def test_decode_audio_reads_flac_natively():
     head = open(os.path.join(GOLDEN, "flac_jfk_head.flac"), "rb").read()
     a = decode_audio(head)
     assert a.shape == (-(-36864 * 160 // 441),) and np.isfinite(a).all() and np.abs(a).max() <= 1.0
+
+
+def test_streamed_digital_silence_and_truncation_warning():
+    """A streamed encode (STREAMINFO total = 0) of digital silence: CONSTANT subframes code 4 608 samples per ~14-byte frame,
+    far more than any bytes-per-sample bound allows for — the reader grows its output instead of failing with "too small".
+    A stream cut short of its announced length is returned with a warning (FFmpeg, the reference's decoder, also keeps going)."""
+    import warnings
+    from faster_whisper_amd.audio import _read_flac
+    bs, nb = 4608, 40
+    pcm = np.zeros((bs * nb, 1), np.int64)
+    blocks = [(bs, [dict(kind="const")], None, 5)] * nb            # block code 5 = 4 608 samples, 8-bit-free header
+    data = _stream(pcm, 16, 16000, blocks, known_length=False)
+    assert 16 * len(data) < bs * nb                                # the first guess IS too small
+    x, rate = _read_flac(data)
+    assert rate == 16000 and x.shape == (bs * nb, 1) and not x.any()
+    known = _stream(pcm, 16, 16000, blocks, known_length=True)
+    cut = known[:len(known) - 3 * (len(known) - len(known[:known.index(b"\xff\xf8")])) // nb]   # drop the last frames
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        y, _ = _read_flac(cut)
+    assert 0 < y.shape[0] < bs * nb and y.shape[0] % bs == 0
+    assert any("samples STREAMINFO announces" in str(w.message) for w in rec)
