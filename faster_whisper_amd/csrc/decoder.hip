@@ -591,6 +591,15 @@ static bool mergeable(const GenRequest& a, const GenRequest& b) {
 }
 
 // chunks of a run led by `r` that fit the self-attention cache (before the workspace exists: its planned size)
+// share (percent) of a run's capacity an IDLE decode group (no run in progress) waits for; FWAMD_IDLE_FILL_PCT overrides
+static int idle_fill_pct() {
+  static const int v = [] {
+    const char* e = getenv("FWAMD_IDLE_FILL_PCT");
+    const int x = e ? atoi(e) : 100;
+    return x < 1 ? 1 : (x > 100 ? 100 : x);
+  }();
+  return v;
+}
 static int64_t planned_self_cap(const Model* dm) {   // rows x positions of a lane's self-attention cache
   const int B = lane_chunks_of(dm);
   const int nts = self_positions(dm, B, dm->decode_self_ctx > 0 ? dm->decode_self_ctx : dm->cfg.n_text_ctx);
@@ -964,7 +973,12 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
         int queued = 0;
         for (const GenRequest* r : grp.queue) queued += r->B;
         const int64_t want = std::min<int64_t>(cap, std::max<int64_t>(dm->max_batch, DEC_RUN_MAX_ROWS / std::max(1, grp.queue.front()->o->beam_size)));
-        if ((int64_t)queued * 100 >= want * fill_pct || grp.encoding.load() <= 0) break;
+        // no run in progress at all: every further request waited for is decode time the chip spends idle on the HBM
+        // side (the encoders are MFMA-bound), so an idle group leads with a smaller share of a run's capacity
+        // (idle_fill_pct(): the driver's 20-step burst was ONE run of 288 chunks after 18 serial encoder passes plus two
+        // runs of 16 chunks; with 50 % it is two runs of 160 chunks, the second gathered under the first)
+        const int pct = grp.active_runs == 0 ? std::min(fill_pct, idle_fill_pct()) : fill_pct;
+        if ((int64_t)queued * 100 >= want * pct || grp.encoding.load() <= 0) break;
         if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(wait_ms)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
       }
