@@ -600,6 +600,11 @@ static int idle_fill_pct() {
   }();
   return v;
 }
+// FWAMD_IDLE_BALANCE=1: an idle two-lane group splits the known work evenly over its runs (see the gather loop)
+static bool idle_balance() {
+  static const bool v = [] { const char* e = getenv("FWAMD_IDLE_BALANCE"); return e && atoi(e) != 0; }();
+  return v;
+}
 static int64_t planned_self_cap(const Model* dm) {   // rows x positions of a lane's self-attention cache
   const int B = lane_chunks_of(dm);
   const int nts = self_positions(dm, B, dm->decode_self_ctx > 0 ? dm->decode_self_ctx : dm->cfg.n_text_ctx);
@@ -979,6 +984,15 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
         // runs of 16 chunks; with 50 % it is two runs of 160 chunks, the second gathered under the first)
         const int pct = grp.active_runs == 0 ? std::min(fill_pct, idle_fill_pct()) : fill_pct;
         if ((int64_t)queued * 100 >= want * pct || grp.encoding.load() <= 0) break;
+        // ... and with two lanes it splits the work it KNOWS of evenly over the runs that work needs: what is queued plus
+        // one request per worker that is inside an encode call (running or waiting for the encoder; counted at the size of
+        // the queued requests).  20 batches in flight -> two runs of 10, not one of 18 and leftovers.
+        if (idle_balance() && grp.active_runs == 0 && n_lanes >= 2 && grp.lanes_enabled.load() >= 2) {
+          const int64_t per_req = std::max<int64_t>(1, queued / std::max<int64_t>(1, (int64_t)grp.queue.size()));
+          const int64_t outstanding = queued + (int64_t)grp.encoding.load() * per_req;
+          const int64_t n_runs = std::max<int64_t>(2, (outstanding + want - 1) / want);
+          if (queued >= std::max<int64_t>(dm->max_batch, (outstanding + n_runs - 1) / n_runs)) break;
+        }
         if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(wait_ms)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
       }
