@@ -307,6 +307,20 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48, long_steps=0, logits_r
 _LAST = {}
 
 
+_ENC32 = {}
+
+
+def _encode32(o32, cfg, w, chunks):
+    """the fp32 oracle's own encoder output of the SUBSET chunks (its own log-mel), computed once per geometry / weights:
+    two tests of a geometry ask for it (a large-v3 encoder pass of two chunks is ~20 s of host time)"""
+    from oracle.logmel import log_mel_chunks
+    key = (cfg.name, id(w))
+    if key not in _ENC32:
+        _ENC32.clear()
+        _ENC32[key] = o32.encode(log_mel_chunks([chunks[b] for b in SUBSET], cfg.n_mels))
+    return _ENC32[key]
+
+
 def _fp32_leg(cfg, w, compute_type, tag, expect, chunks, enc_engine, prompt, sup, tf_steps, beam_steps, g1, g5, gl, ga,
               text, nf, names):
     """BASELINE.json: "outputs match the reference CTranslate2 CPU path" — fp32 arithmetic.  The oracle WITHOUT fp16
@@ -316,11 +330,10 @@ def _fp32_leg(cfg, w, compute_type, tag, expect, chunks, enc_engine, prompt, sup
     the language and the align probabilities.  The engine's figures are the ones checked above against the fp16-emulating
     oracle; what is measured here is the engine's whole distance from fp32.  Printed always; asserted at NORTH_STAR
     except for the entries of EXCEPTIONS_FP32."""
-    from oracle.logmel import log_mel_chunks
     o32 = _oracle(cfg, w, False, fp32=True)
     t32 = {k: tolerance_fp32(cfg.name, compute_type, k) for k in ("tf", "beam", "nsp", "lang", "align")}
     tag = f"{tag} vs fp32"
-    enc32 = o32.encode(log_mel_chunks([chunks[b] for b in SUBSET], cfg.n_mels))
+    enc32 = _encode32(o32, cfg, w, chunks)
     kw1 = dict(beam_size=1, max_length=len(prompt) + tf_steps, length_penalty=0.0, suppress_tokens=sup)
     kw5 = dict(beam_size=5, patience=1.0, length_penalty=1.0, max_length=len(prompt) + beam_steps, suppress_tokens=sup)
     rl = o32.detect_language(enc32)
@@ -596,12 +609,11 @@ def test_peaked_greedy_literal_ids_large_v3_float16(lv3):
         assert all(len(g.sequences_ids[0]) == steps for g in g1)
         # ---- the same claim against the fp32 oracle END TO END (the reference's CPU path: fp32 arithmetic, its own log-mel
         # and encoder output): every id the engine emitted is the fp32 arg-max, margins far above the fp16 noise ----
-        from oracle.logmel import log_mel_chunks
         o32 = _oracle(cfg, w, False, fp32=True)
         keep32 = o32.w["dec.pos"]
         o32.w["dec.pos"] = torch.from_numpy(wp["dec.pos"].astype(np.float32))
         try:
-            enc32 = o32.encode(log_mel_chunks([chunks[b] for b in SUBSET], cfg.n_mels))
+            enc32 = _encode32(o32, cfg, w, chunks)     # (the peaked variant differs in dec.pos only: same encoder)
             for j, b in enumerate(SUBSET):
                 ids = g1[b].sequences_ids[0]
                 r = forced_result(o32, enc32[j], prompt, ids, kw)
