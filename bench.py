@@ -223,7 +223,7 @@ def parse_args(argv=None):
                     help="share (percent) of a decode run's chunk capacity the leader of a run waits for (backend default 90)")
     ap.add_argument("--merge-wait-ms", type=int, default=None,
                     help="how long the leader of a decode run waits after the last arrival for workers that are still encoding "
-                         "(backend default: one measured encoder pass, at most 120 ms)")
+                         "(backend default: 2.5 measured encoder passes, at most 250 ms)")
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
                     help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
     ap.add_argument("--word-timestamps", action="store_true",

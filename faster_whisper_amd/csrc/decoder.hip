@@ -600,9 +600,10 @@ static int idle_fill_pct() {
   }();
   return v;
 }
-// FWAMD_IDLE_BALANCE=1: an idle two-lane group splits the known work evenly over its runs (see the gather loop)
+// an idle two-lane group splits the known work evenly over its runs (see the gather loop); FWAMD_IDLE_BALANCE=0 turns it
+// off (the A/B of profiles/r05_ab_idle_balance.jsonl: burst 2 904 -> 2 976x, steady state 3 105 -> 3 105x)
 static bool idle_balance() {
-  static const bool v = [] { const char* e = getenv("FWAMD_IDLE_BALANCE"); return e && atoi(e) != 0; }();
+  static const bool v = [] { const char* e = getenv("FWAMD_IDLE_BALANCE"); return !e || atoi(e) != 0; }();
   return v;
 }
 static int64_t planned_self_cap(const Model* dm) {   // rows x positions of a lane's self-attention cache
@@ -965,13 +966,16 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     // lead the next run: wait for the requests of workers that are still encoding (each arrives within one
     // encoder pass) unless most of a run's capacity is already claimed, then take every queued request that can share
     // a run with the oldest one.  The wait trades this caller's latency for rows per run; it is bounded by the
-    // merge-wait knob (fw_model_set_merge_wait: default one measured encoder pass after the last arrival, at most
-    // 120 ms; 0 = never) and skipped when no member encode is in flight.  One caller gathers at a time; with two lanes
+    // merge-wait knob (fw_model_set_merge_wait: default 2.5 measured encoder passes after the last arrival, at most
+    // 250 ms — a pass next to a decode run takes up to twice the pass the average was taken from, and a leader that
+    // gives up between two arrivals starts a run of one or two batches: the driver's 20-step burst 2 976 -> 3 030x with
+    // 150 or 250 ms, the steady state unchanged, profiles/r05_ab_idle_balance.jsonl; 0 = never) and skipped when no
+    // member encode is in flight.  One caller gathers at a time; with two lanes
     // the next one starts gathering as soon as this one has taken its requests and gone off to run them.
     grp.gathering = true;
     const int cap = lane_chunks_of(dm);
     int wait_ms = grp.merge_wait_ms.load();
-    if (wait_ms < 0) wait_ms = std::min(120, std::max(5, (grp.enc_pass_us.load() * 5 / 4 + 999) / 1000));
+    if (wait_ms < 0) wait_ms = std::min(250, std::max(5, (grp.enc_pass_us.load() * 5 / 2 + 999) / 1000));
     const int fill_pct = grp.merge_fill_pct.load();
     if (cap > dm->max_batch && wait_ms > 0 && !grp.queue.front()->sampling) {
       for (;;) {

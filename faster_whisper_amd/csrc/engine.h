@@ -115,7 +115,7 @@ struct DecodeGroup {
   std::chrono::steady_clock::time_point last_arrival{};   // when the newest request was queued
   std::mutex enc_mu;              // one encoder pass at a time per device
   std::atomic<int> enc_pass_us{0};   // running mean of the time a member holds enc_mu (one encoder pass)
-  std::atomic<int> merge_wait_ms{-1};   // fw_model_set_merge_wait: -1 = one encoder pass (<= 120 ms), 0 = never wait
+  std::atomic<int> merge_wait_ms{-1};   // fw_model_set_merge_wait: -1 = 2.5 encoder passes (<= 250 ms), 0 = never wait
   std::atomic<int> merge_fill_pct{90};  // ... and the share of a run's chunk capacity at which the leader stops waiting
   // statistics (fw_model_decode_stats): decode runs, fw_generate calls served, chunks decoded, largest run
   std::atomic<int64_t> n_runs{0}, n_requests{0}, n_chunks{0};

@@ -180,11 +180,14 @@ int32_t fw_model_decode_batch(const fw_model* m);
 int32_t fw_model_run_capacity(const fw_model* m);
 int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
 /* How long, and for how much, the leader of a decode run waits for the requests of workers that are still encoding
- * (latency of the waiting call against rows per run).  wait_ms: -1 = one measured encoder pass after the last arrival,
- * at most 120 ms (default); 0 = never wait (every call starts its run at once: lowest latency); n > 0 = n milliseconds.
+ * (latency of the waiting call against rows per run).  wait_ms: -1 = 2.5 measured encoder passes after the last arrival,
+ * at most 250 ms (default); 0 = never wait (every call starts its run at once: lowest latency); n > 0 = n milliseconds.
  * fill_percent: the leader stops waiting once that share of a run's chunk capacity is queued (default 90: large runs
  * amortise the decoder weights and launches over more rows and take the GEMM-shaped decoder linears; measured 2 917x
- * at 50, 2 965x at 75, 2 975x at 95; smaller = lower latency).  It never waits when no member encode is in flight. */
+ * at 50, 2 965x at 75, 2 975x at 95; smaller = lower latency).  It never waits when no member encode is in flight.  A group with NO run in progress and two
+ * lanes leads earlier: it splits the work it knows of (queued requests + one per worker inside an encode call) evenly over
+ * the runs that work needs — 20 batches in flight become two runs of 10 instead of one of 18 after 18 serial encoder
+ * passes and leftovers (FWAMD_IDLE_BALANCE=0 restores the plain rule). */
 int32_t fw_model_set_merge_wait(fw_model* m, int32_t wait_ms, int32_t fill_percent);
 /* Decode runs the group may have in flight: 2 (default, when the group has two lanes) or 1 (one run at a time: every
  * kernel of a run has the chip to itself — what per-kernel timing wants; takes effect with the next run). */
