@@ -226,7 +226,9 @@ class Whisper:
                 "there is no CPU path")
         if compute_type not in _COMPUTE_TYPES:
             raise ValueError(f"unsupported compute_type '{compute_type}' (supported: float16, int8_float16)")
-        self._compute_type_name = "float16" if compute_type in ("default", "auto") else compute_type
+        # the RESOLVED type, as ctranslate2's `compute_type` property reports it ("int8" on a device with fp16 -> int8_float16)
+        self._compute_type_name = {"default": "float16", "auto": "float16",
+                                   "int8": "int8_float16"}.get(compute_type, compute_type)
         ct = _COMPUTE_TYPES[compute_type]
         if files and "config" in files:
             cfg, weights = files["config"], files.get("weights")

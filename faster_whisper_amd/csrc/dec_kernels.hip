@@ -728,18 +728,35 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
     const int row = (rt0 + a) * 16 + i;
     if (rt0 + a >= n_rt || row >= R) continue;
     const float sx = I8 ? x_scale[row] : 1.f;
+    const bool pair_ok = (ldo & 1) == 0;      // (wave-uniform) every row starts 8-byte aligned
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       if (ct0 + b >= n_ct) continue;
       const int n = (ct0 + b) * 16 + 4 * g;   // this lane: D[n + e][row], e = 0..3
+      float t4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ne = n + e < N ? n + e : N - 1;   // (clamped: computed, never stored)
+        float tv = I8 ? (float)acci[a][b][e] * sx * w_scale[ne] : accf[a][b][e];
+        if (LNF) tv = rstd * (tv - mu * s1[ne]) + cf[ne];
+        else if (bias) tv += (float)bias[ne];
+        t4[e] = tv;
+      }
+      if (F32 && pair_ok) {
+        // a lane's four logits are consecutive columns of one row: two 8-byte stores (n and ldo are even: aligned)
+        // instead of four 4-byte ones — 265 MB of logits leave a 1 280-row step through 40 store instructions per wave
+        float* o = reinterpret_cast<float*>(outv) + (size_t)row * ldo + n;
+        if (n + 1 < N) *reinterpret_cast<floatx2*>(o) = floatx2{t4[0], t4[1]};
+        else if (n < N) o[0] = t4[0];
+        if (n + 3 < N) *reinterpret_cast<floatx2*>(o + 2) = floatx2{t4[2], t4[3]};
+        else if (n + 2 < N) o[2] = t4[2];
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (n + e >= N) continue;
-        float tv = I8 ? (float)acci[a][b][e] * sx * w_scale[n + e] : accf[a][b][e];
-        if (LNF) tv = rstd * (tv - mu * s1[n + e]) + cf[n + e];
-        else if (bias) tv += (float)bias[n + e];
-        if (F32) reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = tv;
-        else reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)tv;
+        if (F32) reinterpret_cast<float*>(outv)[(size_t)row * ldo + n + e] = t4[e];
+        else reinterpret_cast<half_t*>(outv)[(size_t)row * ldo + n + e] = (half_t)t4[e];
       }
     }
   }
