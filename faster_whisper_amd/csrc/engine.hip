@@ -1849,8 +1849,9 @@ int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {
-  FW_CHECK_ARG(id == 1 || id == 2 || id == 4, "unknown knob %d", id);
+  FW_CHECK_ARG(id == 1 || id == 2 || id == 4 || id == 5, "unknown knob %d", id);
   if (id == 1) fwk::g_gemm_order.store(value);
+  else if (id == 5) fwk::g_gemm_vt_stage.store(value);
   else if (id == 2) fwd::set_self_attn_form(value);
   else set_pos_blocks(value);
   return FW_OK;
@@ -1961,7 +1962,10 @@ int32_t fw_bench_gemm(fw_model* fm, int32_t M, int32_t N, int32_t K, int32_t bat
   const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   const int64_t lda = K + a_pad, ldw = K + w_pad;
   const size_t es = i8 ? 1 : 2;
-  const size_t na = (size_t)batch * M * lda, nw = (size_t)N * ldw, nc = (size_t)batch * M * N;
+  // transposed output: Ct[z][n][m] with the row stride the encoder's V^T has (keys padded to a multiple of 64: t_pad)
+  const int64_t ldct = (M + 63) / 64 * 64;
+  const size_t na = (size_t)batch * M * lda, nw = (size_t)N * ldw,
+               nc = trans ? (size_t)batch * N * ldct : (size_t)batch * M * N;
   void *dA = nullptr, *dW = nullptr;
   half_t* dC = nullptr;
   float *dsa = nullptr, *dsw = nullptr;
@@ -1984,7 +1988,7 @@ int32_t fw_bench_gemm(fw_model* fm, int32_t M, int32_t N, int32_t K, int32_t bat
   memset(&p, 0, sizeof(p));
   p.A = (const half_t*)dA; p.lda = lda; p.a_bstride = (int64_t)M * lda;
   p.W = (const half_t*)dW; p.ldw = ldw;
-  p.C = dC; p.ldc = trans ? M : N; p.c_bstride = (int64_t)M * N;
+  p.C = dC; p.ldc = trans ? ldct : N; p.c_bstride = trans ? (int64_t)N * ldct : (int64_t)M * N;
   p.M = M; p.N = N; p.K = K;
   p.a_scale = dsa; p.as_bstride = M; p.w_scale = dsw;
   hipEvent_t e0, e1;

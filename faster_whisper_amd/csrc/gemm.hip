@@ -427,6 +427,57 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
         }
       }
     }
+  } else if (TRANS && !I8 && p.vt_stage) {
+    // Plain transposed output Ct[z][n][m] (the encoder's V^T, [d][t_pad] per chunk: what attn_enc_kernel multiplies P
+    // with).  The accumulator hands a lane 4 consecutive m of ONE column n: stored directly that is 32 eight-byte stores
+    // per lane, each instruction into 32 different rows of Ct (the store-issue-bound pattern the other two epilogues left
+    // in rounds 2 and 4).  The wave's 128 (m) x 64 (n) sub-tile goes through its 17 KB patch of the idle ring as fp16
+    // [n][m] — same arithmetic per element as the direct form below, so the same bits — and leaves as whole 256-byte
+    // row segments of Ct, 16 B per lane.  Columns m >= M of Ct (the padding up to t_pad) are never written, as before.
+    // (fp16 only: in the int8 instantiation the staged form next to the direct one spills 38 registers — the per-row
+    //  de-quantisation factors are loads of their own — so int8_float16 keeps the direct stores.)
+    constexpr int TS = 272;                                  // bytes per staged row: 128 halves + 16
+    char* ep = smem_raw + wave * (64 * TS);
+    half_t* Cb = p.C + (size_t)z * p.c_bstride;
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int c = ni * 32 + l31;                           // column of the sub-tile = row of the staged patch
+      int n = nw + c; if (n > p.N - 1) n = p.N - 1;          // clamped columns are never stored
+      const float bv = p.bias ? (float)p.bias[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r = mi * 32 + 8 * g + 4 * hi;            // 4 consecutive m inside the sub-tile
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = accf[mi][ni][g * 4 + e] + bv;
+            if (p.act == 1) v = gelu_erf(v);
+            o[e] = (half_t)v;
+          }
+          *reinterpret_cast<half4_t*>(ep + c * TS + r * 2) = o;
+        }
+    }
+    // (a wave's LDS operations execute in order: the reads below see the writes above)
+    const int rr = lane >> 4, cc = (lane & 15) * 8;          // 16 lanes per staged row, 8 m each
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int c = j * 4 + rr;
+      const int n = nw + c, m = mw + cc;
+      const intx4 v = *reinterpret_cast<const intx4*>(ep + c * TS + cc * 2);
+      if (n >= p.N || m >= p.M) continue;
+      half_t* dst = Cb + (size_t)n * p.ldc + m;
+      if (m + 8 <= p.M) {
+        *reinterpret_cast<intx4*>(dst) = v;
+      } else {
+        const half8_t h = __builtin_bit_cast(half8_t, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (m + e < p.M) dst[e] = h[e];
+      }
+    }
   } else {
     half_t* Cb = p.C + (size_t)z * p.c_bstride;  // Ct[z][n][m], ldc = row stride of Ct
 #pragma unroll
@@ -466,6 +517,8 @@ namespace fwk {
 // tile order of launch_gemm: 1 = blocked (the product), 0 = n fastest across the whole width (rounds 1-3); a process-wide
 // knob for the A/B of profiles/gemm_bench.py (fw_test_knob)
 std::atomic<int> g_gemm_order{1};
+// plain V^T epilogue: 1 = staged through LDS (the product), 0 = direct stores (rounds 1-4); knob 5 of fw_test_knob
+std::atomic<int> g_gemm_vt_stage{1};
 
 int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   GemmParams p = pin;
@@ -479,6 +532,9 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   p.nNt = (p.N + GB_N - 1) / GB_N;
   p.n_mp = p.nMt * batch;
   p.blk_m = p.blk_n = 0;
+  // (16-byte row segments of Ct need ldc and the batch stride to be multiples of 8 halves)
+  p.vt_stage = (trans && !i8 && p.head_rows == 0 && g_gemm_vt_stage.load(std::memory_order_relaxed) == 1 && p.ldc % 8 == 0 &&
+                p.c_bstride % 8 == 0) ? 1 : 0;
   if (g_gemm_order.load(std::memory_order_relaxed) == 1 && p.nNt > 1 && p.n_mp > 1) {
     // L2 fill traffic of a block of bm x bn tiles that an XCD's 32 workgroups run in near lockstep is (bm + bn) operand
     // panels (measured: the out-projection, 6.4 + 5 panels per 32 tiles, fetches 119 MB = that model's 112; the FFN-up

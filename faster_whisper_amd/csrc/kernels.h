@@ -29,9 +29,11 @@ struct GemmParams {
   const float* a_scale; int64_t as_bstride; const float* w_scale;
   int nMt, nNt;                                       // filled by launch_gemm
   int n_mp, blk_m, blk_n;                             // ... m panels of the whole batch, tile-order block (gemm.hip)
+  int vt_stage;                                       // ... TRANS, plain Ct: epilogue staged through LDS (gemm.hip), 0 = direct stores
 };
 int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
 extern std::atomic<int> g_gemm_order;                 // tile order knob (gemm.hip), for A/B measurements only
+extern std::atomic<int> g_gemm_vt_stage;              // 1 (product): the plain V^T epilogue goes through LDS; 0: direct stores (A/B)
 
 // ---- row kernels (rowops.hip) -----------------------------------------------------
 // y[r] = LN(x[r]) * g + b, eps 1e-5, fp32 statistics (two-pass in registers)

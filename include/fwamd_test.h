@@ -61,7 +61,9 @@ int32_t fw_dec_big_min_rows(void);
  * product's; 0 = n fastest across the whole width, rounds 1-3).  id 2: decoder self-attention form (0 = by launch size,
  * the product's; 1 = the first form of rounds 1-4; 2 = latency form; 3 = throughput form — all four return the same bits).  id 4 (3 was the weight prefetch of
  * solo runs, measured slower twice and removed: profiles/r05_ab_wprefetch_*.jsonl): position blocks for the prompt forward and align (1, the default:
- * up to 16 positions per decoder pass; 0: one position per pass, rounds 1-4 — the same bits) */
+ * up to 16 positions per decoder pass; 0: one position per pass, rounds 1-4 — the same bits).  id 5: the plain transposed
+ * GEMM epilogue, i.e. the encoder's V^T (1, the default: staged through LDS, whole row segments of Ct; 0: direct 8-byte stores,
+ * rounds 1-4 — the same bits) */
 int32_t fw_test_knob(int32_t id, int32_t value);
 
 #ifdef __cplusplus

@@ -87,6 +87,34 @@ def test_gemm_transposed_output(model, M, N, K):
     assert err < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(1504, 256, 128), (296, 128, 128), (1024, 512, 64), (2048, 200, 192)])
+def test_gemm_transposed_output_staged_epilogue(model, M, N, K):
+    """Round 5: the plain transposed epilogue (the encoder's V^T) goes through LDS and leaves as 256-byte row segments
+    of Ct when the row stride allows 16-byte stores (here ldc = M, so M % 8 == 0 takes the staged form; the shapes of
+    the test above have M % 8 != 0 and keep the direct stores).  Same arithmetic per element: the staged result equals
+    the direct one (fw_test_knob 5 = 0) bit for bit, and the fp32 reference within fp16 round-off; N = 200 leaves the
+    last column tile ragged (columns >= N are staged but never stored)."""
+    from faster_whisper_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N)
+    A = _h(rng.standard_normal((M, K)).astype(np.float32))
+    W = _h((rng.standard_normal((N, K)) * (1.0 + np.arange(N)[:, None] / N)).astype(np.float32))
+    b = _h(rng.standard_normal(N).astype(np.float32))
+    out = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.fw_test_knob(5, on))
+            out[on] = _gemm(model, A, W, bias=b, act=2)      # [N][M]
+    finally:
+        _lib.check(lib.fw_test_knob(5, 1))
+    ref = (A @ W.T + b).T
+    err = np.abs(out[1] - ref).max() / np.abs(ref).max()
+    print(f"gemm transposed, staged epilogue {M}x{N}x{K}: rel err {err:.2e}; identical to the direct stores: "
+          f"{np.array_equal(out[0], out[1])}")
+    assert err < 2e-3
+    assert np.array_equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("d", [128, 384, 1280])
 def test_layernorm(model, d):
     from faster_whisper_amd import _lib

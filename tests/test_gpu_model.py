@@ -404,6 +404,26 @@ def test_self_attention_forms_return_the_same_bits(setup):
     print(f"[{cfg.name}] self-attention forms 1 / 2 / 3 / auto: identical ids, scores and no-speech bits over 3 configurations")
 
 
+def test_encoder_vt_epilogue_same_bits(setup):
+    """Round 5 (fw_test_knob 5, default on): the encoder's V^T projection stores its transposed tile through LDS in whole
+    row segments of Ct [d][t_pad] (M = 1 500 keys, row stride 1 536: the last 16-byte chunk of a row is partial, the padding
+    columns are never written) instead of 32 scattered 8-byte stores per lane.  Same arithmetic per element: the encoder
+    output — every layer's attention reads V^T — may not move by a bit, ragged and empty chunks included."""
+    from faster_whisper_amd import _lib
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    lib = _lib.load()
+    out = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.fw_test_knob(5, on))
+            out[on] = model.encode(StorageView.from_array(feats)).to_numpy()
+    finally:
+        _lib.check(lib.fw_test_knob(5, 1))
+    assert np.isfinite(out[1]).all() and np.array_equal(out[0], out[1])
+    print(f"[{cfg.name}] encoder output with the staged / direct V^T epilogue: bit-identical")
+
+
 def test_position_blocks_same_bits(setup):
     """Round 5 (fw_test_knob 4, default on): the prompt forward of `generate` and the teacher-forced pass of `align` go
     through the decoder in blocks of up to 16 positions per pass (rows = chunks x positions; a sibling position's K / V
