@@ -68,6 +68,7 @@ SYMBOLS = [
     "fw_model_create", "fw_model_free", "fw_model_info", "fw_model_blob", "fw_model_create_from_blob_dev",
     "fw_model_set_decode_batch", "fw_model_decode_batch", "fw_model_join_decoder", "fw_model_decode_stats",
     "fw_model_set_merge_wait", "fw_model_set_decode_lanes", "fw_model_run_capacity", "fw_dec_big_min_rows", "fw_test_knob",
+    "fw_test_idle_lead_chunks",
     "fw_pack_blob_size", "fw_pack_blob_copy", "fw_pack_blob_free",
     "fw_logmel", "fw_logmel_full",
     "fw_encode", "fw_encode_pcm", "fw_encode_pcm_dev", "fw_tensor_shape", "fw_tensor_to_host",
@@ -119,6 +120,9 @@ def load():
         lib.fw_flac_decode.argtypes = [vp, i64, vp, i64, i64p, i32p]
     if hasattr(lib, "fw_test_knob"):          # (absent from the older build an A/B loads through FWAMD_LIB)
         lib.fw_test_knob.argtypes = [i32, i32]
+    if hasattr(lib, "fw_test_idle_lead_chunks"):
+        lib.fw_test_idle_lead_chunks.argtypes = [i64, i32, i32, i64, i32]
+        lib.fw_test_idle_lead_chunks.restype = i64
     lib.fw_model_join_decoder.argtypes = [vp, vp]
     lib.fw_model_set_merge_wait.argtypes = [vp, i32, i32]
     lib.fw_model_set_decode_lanes.argtypes = [vp, i32]

@@ -606,6 +606,15 @@ static bool idle_balance() {
   static const bool v = [] { const char* e = getenv("FWAMD_IDLE_BALANCE"); return !e || atoi(e) != 0; }();
   return v;
 }
+// chunks an IDLE two-lane group wants queued before it leads a run: its even share of the work it knows of — `queued`
+// chunks in `n_queued` requests plus one request of that average size per worker inside an encode call — over the runs
+// that work needs (at least two: one per lane; more when it exceeds two runs' capacity `want`), never less than one batch
+int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch) {
+  const int64_t per_req = std::max<int64_t>(1, queued / std::max<int64_t>(1, (int64_t)n_queued));
+  const int64_t outstanding = queued + (int64_t)std::max(0, encoding) * per_req;
+  const int64_t n_runs = std::max<int64_t>(2, (outstanding + std::max<int64_t>(1, want) - 1) / std::max<int64_t>(1, want));
+  return std::max<int64_t>(max_batch, (outstanding + n_runs - 1) / n_runs);
+}
 static int64_t planned_self_cap(const Model* dm) {   // rows x positions of a lane's self-attention cache
   const int B = lane_chunks_of(dm);
   const int nts = self_positions(dm, B, dm->decode_self_ctx > 0 ? dm->decode_self_ctx : dm->cfg.n_text_ctx);
@@ -991,12 +1000,9 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
         // ... and with two lanes it splits the work it KNOWS of evenly over the runs that work needs: what is queued plus
         // one request per worker that is inside an encode call (running or waiting for the encoder; counted at the size of
         // the queued requests).  20 batches in flight -> two runs of 10, not one of 18 and leftovers.
-        if (idle_balance() && grp.active_runs == 0 && n_lanes >= 2 && grp.lanes_enabled.load() >= 2) {
-          const int64_t per_req = std::max<int64_t>(1, queued / std::max<int64_t>(1, (int64_t)grp.queue.size()));
-          const int64_t outstanding = queued + (int64_t)grp.encoding.load() * per_req;
-          const int64_t n_runs = std::max<int64_t>(2, (outstanding + want - 1) / want);
-          if (queued >= std::max<int64_t>(dm->max_batch, (outstanding + n_runs - 1) / n_runs)) break;
-        }
+        if (idle_balance() && grp.active_runs == 0 && n_lanes >= 2 && grp.lanes_enabled.load() >= 2 &&
+            queued >= idle_lead_chunks(queued, (int)grp.queue.size(), grp.encoding.load(), want, dm->max_batch))
+          break;
         if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(wait_ms)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
       }

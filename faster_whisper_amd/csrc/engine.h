@@ -231,6 +231,8 @@ int dev_alloc(void** p, size_t bytes);
 // neither shares a hardware queue with the encoder streams of the workers nor waits behind their workgroups when a CU
 // frees up.  Measurement knob: FWAMD_DEC_STREAM_PRIO (decode lanes), FWAMD_ENC_STREAM_PRIO (encoder / replica streams).
 hipError_t create_stream(hipStream_t* st, const char* env);
+// decode groups (decoder.hip): chunks an idle two-lane group waits for before it leads a run
+int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch);
 template <typename T>
 inline int dev_alloc_t(T** p, size_t n) { return dev_alloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
 

@@ -1857,6 +1857,11 @@ int32_t fw_test_knob(int32_t id, int32_t value) {
   return FW_OK;
 }
 
+// host-only: the run size an idle two-lane decode group leads with (decoder.hip: idle_lead_chunks); needs no device
+int64_t fw_test_idle_lead_chunks(int64_t queued, int32_t n_queued, int32_t encoding, int64_t want, int32_t max_batch) {
+  return idle_lead_chunks(queued, n_queued, encoding, want, max_batch);
+}
+
 int32_t fw_test_dec_logits(fw_model* fm, const float* x, int32_t R, float* out) {
   FW_CHECK_ARG(fm && x && out && R >= 1, "bad argument");
   Model* m = &fm->impl;

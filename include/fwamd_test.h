@@ -65,6 +65,11 @@ int32_t fw_dec_big_min_rows(void);
  * GEMM epilogue, i.e. the encoder's V^T (1, the default: staged through LDS, whole row segments of Ct; 0: direct 8-byte stores,
  * rounds 1-4 — the same bits) */
 int32_t fw_test_knob(int32_t id, int32_t value);
+/* host-only (no device needed): chunks an IDLE two-lane decode group wants queued before it leads a run — its even share of
+ * the work it knows of (`queued` chunks in `n_queued` requests + one request of that average size per worker inside an encode
+ * call) over the runs that work needs (>= 2; `want` = chunks one run takes), at least one batch.  The rule the leader of a
+ * run applies when no run is in progress (fw_model_set_merge_wait, include/fwamd.h). */
+int64_t fw_test_idle_lead_chunks(int64_t queued, int32_t n_queued, int32_t encoding, int64_t want, int32_t max_batch);
 
 #ifdef __cplusplus
 }

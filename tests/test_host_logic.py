@@ -123,3 +123,27 @@ def test_bench_pipeline_measure_runs_on_a_scripted_backend():
     r = bench.pipeline_rtf(backend, cfg, 7, 2, 5, 20)
     assert r["segments"] == 7 and r["tokens"] == 7 * 20 and r["audio_s"] == 210.0 and r["value"] > 0
     assert "error" in bench.pipeline_rtf(object(), cfg, 2, 2, 5, 20)
+
+
+def test_idle_decode_group_splits_known_work_evenly():
+    """Round 5: the run size an IDLE two-lane decode group leads with (csrc/decoder.hip: idle_lead_chunks, through the
+    host-only hook fw_test_idle_lead_chunks — no device involved).  The reference's replica pool decodes batches side by
+    side (transcribe.py:645-657); here the batches of the workers share decode runs, and a group with no run in progress
+    starts its first run at its even share of the work it knows of instead of waiting for 90 % of a run's capacity."""
+    from faster_whisper_amd import _lib
+    f = _lib.load().fw_test_idle_lead_chunks
+    cap = 320                                       # chunks one run takes (1 600 rows at beam 5)
+    # the driver's burst: 20 batches of 16 in flight — k queued, 20 - k still encoding -> lead at 10 batches
+    for k in range(1, 21):
+        assert f(16 * k, k, 20 - k, cap, 16) == 160
+    # all 32 workers in flight: 512 chunks > one run -> two runs of 256 (the plain rule would wait for 288)
+    assert f(16, 1, 31, cap, 16) == 256
+    # more than two runs' worth: ceil(1 000 / 320) = 4 runs of 250
+    assert f(200, 10, 40, cap, 20) == 250
+    # a lone caller / nothing else on its way: its own batch, at least one max_batch
+    assert f(16, 1, 0, cap, 16) == 16
+    assert f(3, 1, 0, cap, 16) == 16
+    # ragged batches: the pending requests are counted at the average size of the queued ones
+    assert f(11 + 16, 2, 2, cap, 16) == (27 + 2 * 13 + 1) // 2
+    # degenerate arguments do not divide by zero
+    assert f(0, 0, 0, 0, 1) == 1 and f(16, 0, -3, cap, 16) == 16
