@@ -318,6 +318,35 @@ void gen_workspace_free(Model* m) {
 
 // K11: cross-attention K / V^T of every decoder layer for the chunks of one encoder output, written to the chunk
 // slots of pool block `blk` (held by the caller; once per encoder output as long as the block is not recycled)
+// cross-K/V projections of ALL decoder layers as two launches (K, V^T) instead of two per layer (fp16; knob 6 /
+// FWAMD_CROSS_KV_LAYERED=0: per layer, rounds 1-4).  The 64 per-layer GEMMs are 24 000 x 1 280 x 1 280 each: 480 tiles =
+// 1.875 rounds of 256 workgroups (the last round 7/8 full) with a prologue / epilogue ramp per launch; as one launch the K
+// (or V^T) projection of a 16-chunk batch is 15 360 tiles = 60 full rounds.  Same tiles, same arithmetic: the same bits.
+static std::atomic<int> g_cross_kv_layered{-1};
+static bool cross_kv_layered() {
+  int v = g_cross_kv_layered.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("FWAMD_CROSS_KV_LAYERED");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+    g_cross_kv_layered.store(v);
+  }
+  return v != 0;
+}
+void set_cross_kv_layered(int on) { g_cross_kv_layered.store(on ? 1 : 0); }
+// element strides between consecutive decoder layers' cross.kv weights / biases when they are uniform (they are for a blob
+// packed by pack_blob: every layer holds the same items at the same sizes), else 0
+static bool cross_kv_strides(const Model* m, int64_t* ws, int64_t* bs) {
+  const int L = m->cfg.n_dec_layers;
+  if (L < 2) return false;
+  const int64_t w1 = m->dec[1].ck.w - m->dec[0].ck.w, b1 = m->dec[1].ck.b - m->dec[0].ck.b;
+  for (int l = 1; l < L; ++l) {
+    if (m->dec[l].ck.w - m->dec[0].ck.w != l * w1 || m->dec[l].cv.w - m->dec[0].cv.w != l * w1) return false;
+    if (m->dec[l].ck.b - m->dec[0].ck.b != l * b1 || m->dec[l].cv.b - m->dec[0].cv.b != l * b1) return false;
+  }
+  *ws = w1; *bs = b1;
+  return w1 > 0;
+}
+
 static int ensure_cross_kv(Model* m, const Tensor* enc, int blk, bool hit) {
   if (hit) return FW_OK;
   GenWorkspace* g = m->gen;
@@ -334,6 +363,20 @@ static int ensure_cross_kv(Model* m, const Tensor* enc, int blk, bool hit) {
   const bool i8 = m->compute_type == FW_COMPUTE_INT8_FLOAT16;
   const int kvp = pool->kvp;
   const int64_t kvs = (int64_t)d * kvp;   // one chunk's K (or V^T): H heads x kvp keys x 64
+  int64_t ws = 0, bs = 0;
+  if (!i8 && cross_kv_layered() && cross_kv_strides(m, &ws, &bs)) {
+    const int64_t cls = (int64_t)pool->n_slots() * kvs;          // a layer's region of the pool
+    half_t* kd = pool->ck + (size_t)b0 * kvs;
+    half_t* vd = pool->cvt + (size_t)b0 * kvs;
+    if ((rc = run_linear_layers(m, m->dec[0].ck, c.n_dec_layers, ws, bs, enc->data, d, xs, kd, d, kvs, cls, T, B, false, kvp, st)))
+      return rc;
+    if ((rc = run_linear_layers(m, m->dec[0].cv, c.n_dec_layers, ws, bs, enc->data, d, xs, vd, kvp, kvs, cls, T, B, true, kvp, st)))
+      return rc;
+    std::lock_guard<std::mutex> lk(pool->mu);
+    pool->blocks[blk].enc_id = enc->id;
+    pool->blocks[blk].n = B;
+    return FW_OK;
+  }
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& L = m->dec[l];
     half_t* kd = pool->ck + ((size_t)l * pool->n_slots() + b0) * kvs;

@@ -248,6 +248,12 @@ int run_linear_i8(Model* m, const LinearW& L, const half_t* A, const LNW* ln, ha
                   hipStream_t st = nullptr, int8_t* xq = nullptr, float* xs = nullptr);
 
 // encoder forward on the channel-last mel image already in m->ws_mel_cl; result into out [B][1500][d]
+// ONE launch for the same linear of `n_layers` consecutive layers on one input (fp16): layer l uses L0.w + l * w_lstride,
+// L0.b + l * b_lstride and writes C + l * c_lstride (element strides); gemm.hip "LAYERED launch"
+int run_linear_layers(Model* m, const LinearW& L0, int n_layers, int64_t w_lstride, int64_t b_lstride, const half_t* A,
+                      int64_t lda, int64_t a_bs, half_t* C, int64_t ldc, int64_t c_bs, int64_t c_lstride, int M, int batch,
+                      bool trans, int head_rows, hipStream_t st);
+void set_cross_kv_layered(int on);                 // decoder.hip: knob 6
 int run_encoder(Model* m, int B, half_t* out);
 
 // decoder entry points (decoder.hip)

@@ -791,6 +791,25 @@ int run_linear(Model* m, const LinearW& L, const half_t* A, int64_t lda, int64_t
   return FW_OK;
 }
 
+int run_linear_layers(Model* m, const LinearW& L0, int n_layers, int64_t w_lstride, int64_t b_lstride, const half_t* A,
+                      int64_t lda, int64_t a_bs, half_t* C, int64_t ldc, int64_t c_bs, int64_t c_lstride, int M, int batch,
+                      bool trans, int head_rows, hipStream_t st) {
+  fwk::GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.a_bstride = a_bs;
+  p.W = L0.w; p.ldw = L0.K;
+  p.bias = L0.b;
+  p.C = C; p.ldc = ldc; p.c_bstride = c_bs;
+  p.M = M; p.N = L0.N; p.K = L0.K;
+  p.head_rows = head_rows;
+  p.n_layers = n_layers; p.w_lstride = w_lstride; p.bias_lstride = b_lstride; p.c_lstride = c_lstride;
+  if (fwk::launch_gemm(st ? st : m->stream, p, batch, trans) != 0) {
+    set_error("layered gemm: unsupported shape M=%d N=%d K=%d layers=%d", M, L0.N, L0.K, n_layers);
+    return FW_ERUNTIME;
+  }
+  return FW_OK;
+}
+
 // int8_float16 linear on "many rows" (K25): per-row dynamic quantisation of A (optionally through the
 // LayerNorm that feeds it), int8 x int8 -> int32 MFMA GEMM, de-quantising epilogue.  A == nullptr reuses the
 // rows quantised by the previous call (fused Q|K and V projections share their input).
@@ -1849,7 +1868,8 @@ int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {
-  FW_CHECK_ARG(id == 1 || id == 2 || id == 4 || id == 5, "unknown knob %d", id);
+  FW_CHECK_ARG(id == 1 || id == 2 || id == 4 || id == 5 || id == 6, "unknown knob %d", id);
+  if (id == 6) { set_cross_kv_layered(value); return FW_OK; }
   if (id == 1) fwk::g_gemm_order.store(value);
   else if (id == 5) fwk::g_gemm_vt_stage.store(value);
   else if (id == 2) fwd::set_self_attn_form(value);

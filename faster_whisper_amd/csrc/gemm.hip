@@ -76,7 +76,7 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 // I8: the int8_float16 path (K25): A and W are int8 (per-row dequant scales a_scale[m], w_scale[n]),
 // v_mfma_i32_32x32x32_i8 accumulates in int32, the epilogue de-quantises.  The tile is defined in BYTES
 // (128-byte rows = 64 halves or 128 int8), so staging, swizzle and fragment reads are shared.
-template <bool TRANS, bool I8>
+template <bool TRANS, bool I8, bool LAYERED = false>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int ES = I8 ? 1 : 2;        // element size
@@ -105,10 +105,16 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
   }
   const int z = mp / p.nMt;
   const int mt = mp - z * p.nMt;
+  // layered launch: the n tile runs over the layers' columns; everything below sees ONE layer (p.N columns, its W / bias / C)
+  // (LAYERED is its own instantiation: the code of the plain launches is what it was)
+  int layer = 0;
+  if (LAYERED) { layer = nt / p.nNt_layer; nt -= layer * p.nNt_layer; }
   const int m0 = mt * GB_M, n0 = nt * GB_N;
 
   const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)z * p.a_bstride * ES;
-  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (LAYERED ? (size_t)layer * p.w_lstride * ES : 0);
+  const half_t* const biasp = (LAYERED && p.bias) ? p.bias + (size_t)layer * p.bias_lstride : p.bias;
+  half_t* const Cp = LAYERED ? p.C + (size_t)layer * p.c_lstride : p.C;
 
   // ---- staging addresses.  A wave DMA instruction fills 64 consecutive 16-byte LDS slots = 8 unit rows; wave w
   // issues pieces w and w + 8 of a unit (unit rows 8*piece .. +7).  Unit row u of A0 is tile row (u>>6)*128 + (u&63)
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
     // pattern) added BEFORE the one rounding to fp16: y = fp16(act(acc + bias) + res), as the oracle states it.
     constexpr int EP_STRIDE = 272;                       // bytes per staged row: 64 floats + 16 (16-B aligned)
     char* ep = smem_raw + wave * (64 * EP_STRIDE);
-    half_t* Cb = p.C + (size_t)z * p.c_bstride;
+    half_t* Cb = Cp + (size_t)z * p.c_bstride;
     const half_t* Rb = p.res ? p.res + (size_t)z * p.r_bstride : nullptr;
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;     // this wave's sub-tile
     const int rr = lane >> 3, cc = (lane & 7) * 8;       // store pass: 8 lanes per row segment, 8 columns each
@@ -293,8 +299,8 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
-            if (p.bias) {
-              const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + n);
+            if (biasp) {
+              const half4_t bv = *reinterpret_cast<const half4_t*>(biasp + n);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
             }
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
     // as fp16 [key][dim] (K) or [dim][key] (V^T), and leaves as whole 1 KB runs, 16 B per lane.
     constexpr int FS = 144;                                  // bytes per staged row: 64 halves + 16
     char* ep = smem_raw + wave * (64 * FS);
-    half_t* Cb = p.C + (size_t)z * p.c_bstride;
+    half_t* Cb = Cp + (size_t)z * p.c_bstride;
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;         // this wave's keys / its head's 64 dims
     if (nw < p.N) {
       half_t* Hb = Cb + (size_t)(nw >> 6) * p.head_rows * 64;
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   float v = I8 ? (float)acci[mi][ni][g * 4 + e] * sam * p.w_scale[n + e] : accf[mi][ni][g * 4 + e];
-                  if (p.bias) v += (float)p.bias[n + e];
+                  if (biasp) v += (float)biasp[n + e];
                   if (p.act == 1) v = gelu_erf(v);
                   o[e] = (half_t)v;
                 }
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
             } else {
               const int c = ni * 32 + l31;                   // dim inside the head
               int n = nw + c; if (n > p.N - 1) n = p.N - 1;
-              const float bv = p.bias ? (float)p.bias[n] : 0.f;
+              const float bv = biasp ? (float)biasp[n] : 0.f;
               const float swn = I8 ? p.w_scale[n] : 1.f;
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
@@ -438,13 +444,13 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
     //  de-quantisation factors are loads of their own — so int8_float16 keeps the direct stores.)
     constexpr int TS = 272;                                  // bytes per staged row: 128 halves + 16
     char* ep = smem_raw + wave * (64 * TS);
-    half_t* Cb = p.C + (size_t)z * p.c_bstride;
+    half_t* Cb = Cp + (size_t)z * p.c_bstride;
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int c = ni * 32 + l31;                           // column of the sub-tile = row of the staged patch
       int n = nw + c; if (n > p.N - 1) n = p.N - 1;          // clamped columns are never stored
-      const float bv = p.bias ? (float)p.bias[n] : 0.f;
+      const float bv = biasp ? (float)biasp[n] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -479,14 +485,14 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(fwk::GemmParams p) {
       }
     }
   } else {
-    half_t* Cb = p.C + (size_t)z * p.c_bstride;  // Ct[z][n][m], ldc = row stride of Ct
+    half_t* Cb = Cp + (size_t)z * p.c_bstride;  // Ct[z][n][m], ldc = row stride of Ct
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int n = n0 + wn * 64 + ni * 32 + l31;
         if (n >= p.N) continue;
-        const float bv = p.bias ? (float)p.bias[n] : 0.f;
+        const float bv = biasp ? (float)biasp[n] : 0.f;
         const float swn = I8 ? p.w_scale[n] : 1.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -529,7 +535,9 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
   if (!trans && ((p.N % 4) || (p.ldc % 4) || (p.c_bstride % 4))) return -1;
   if (i8 && !p.w_scale) return -1;
   p.nMt = (p.M + GB_M - 1) / GB_M;
-  p.nNt = (p.N + GB_N - 1) / GB_N;
+  p.nNt_layer = (p.N + GB_N - 1) / GB_N;
+  if (p.n_layers > 1 && (i8 || p.res)) return -1;      // (the int8 path keeps one launch per layer; no layered residual)
+  p.nNt = p.nNt_layer * (p.n_layers > 1 ? p.n_layers : 1);
   p.n_mp = p.nMt * batch;
   p.blk_m = p.blk_n = 0;
   // (16-byte row segments of Ct need ldc and the batch stride to be multiples of 8 halves)
@@ -565,6 +573,19 @@ int launch_gemm(hipStream_t st, const GemmParams& pin, int batch, bool trans) {
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int grid = p.nMt * p.nNt * batch;
+  if (p.n_layers > 1) {
+    static std::atomic<unsigned long long> attr_l{0};
+    if (!((attr_l.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_l.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    if (trans) gemm_f16_kernel<true, false, true><<<grid, 512, lds, st>>>(p);
+    else gemm_f16_kernel<false, false, true><<<grid, 512, lds, st>>>(p);
+    return 0;
+  }
   if (i8) {
     if (trans) gemm_f16_kernel<true, true><<<grid, 512, lds, st>>>(p);
     else gemm_f16_kernel<false, true><<<grid, 512, lds, st>>>(p);

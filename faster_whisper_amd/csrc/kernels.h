@@ -30,6 +30,12 @@ struct GemmParams {
   int nMt, nNt;                                       // filled by launch_gemm
   int n_mp, blk_m, blk_n;                             // ... m panels of the whole batch, tile-order block (gemm.hip)
   int vt_stage;                                       // ... TRANS, plain Ct: epilogue staged through LDS (gemm.hip), 0 = direct stores
+  // LAYERED launch (n_layers > 1; fp16 only): the same A is multiplied with the W of n_layers layers in ONE launch — the
+  // grid's n tiles run over all layers (n tile t belongs to layer t / nNt_layer), N / bias / C describe ONE layer and
+  // layer l reads W + l * w_lstride, bias + l * bias_lstride and writes C + l * c_lstride (element strides).  Used for the
+  // cross-attention K / V^T projections of all decoder layers (decoder.hip: 2 launches instead of 2 x 32)
+  int n_layers; int64_t w_lstride, bias_lstride, c_lstride;
+  int nNt_layer;                                      // filled by launch_gemm: n tiles of one layer
 };
 int launch_gemm(hipStream_t st, const GemmParams& p, int batch, bool trans);
 extern std::atomic<int> g_gemm_order;                 // tile order knob (gemm.hip), for A/B measurements only

@@ -63,7 +63,8 @@ int32_t fw_dec_big_min_rows(void);
  * solo runs, measured slower twice and removed: profiles/r05_ab_wprefetch_*.jsonl): position blocks for the prompt forward and align (1, the default:
  * up to 16 positions per decoder pass; 0: one position per pass, rounds 1-4 — the same bits).  id 5: the plain transposed
  * GEMM epilogue, i.e. the encoder's V^T (1, the default: staged through LDS, whole row segments of Ct; 0: direct 8-byte stores,
- * rounds 1-4 — the same bits) */
+ * rounds 1-4 — the same bits).  id 6: the cross-attention K / V^T projections (1, the default: all decoder layers in two
+ * launches of the encoder GEMM; 0: two launches per layer, rounds 1-4 — the same bits) */
 int32_t fw_test_knob(int32_t id, int32_t value);
 /* host-only (no device needed): chunks an IDLE two-lane decode group wants queued before it leads a run — its even share of
  * the work it knows of (`queued` chunks in `n_queued` requests + one request of that average size per worker inside an encode

@@ -424,6 +424,44 @@ def test_encoder_vt_epilogue_same_bits(setup):
     print(f"[{cfg.name}] encoder output with the staged / direct V^T epilogue: bit-identical")
 
 
+def test_cross_kv_layered_same_bits(setup):
+    """Round 5 (fw_test_knob 6, default on): the cross-attention K / V^T projections of ALL decoder layers run as two
+    launches of the encoder GEMM (its n tiles run over the layers' weights) instead of two per layer.  Same tiles, same
+    arithmetic per element, same destinations in the pool: generate (beam and greedy), detect_language and align — every
+    consumer of the pool — return the same bits.  Each setting gets a FRESH encoder output, so that the pool cannot hand
+    back the block the other setting filled."""
+    from faster_whisper_amd import _lib
+    from faster_whisper_amd.backend import StorageView
+    cfg, model, oracle, feats = setup
+    lib = _lib.load()
+    rng = np.random.default_rng(45)
+    text = [rng.integers(10, 300, size=n).tolist() for n in (9, 5, 12)]
+    res = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.fw_test_knob(6, on))
+            enc = model.encode(StorageView.from_array(feats))
+            out = []
+            for beam in (5, 1):
+                prompt = _prompt(cfg, True)
+                kw = dict(beam_size=beam, max_length=len(prompt) + 12, suppress_blank=True, suppress_tokens=_suppress(cfg))
+                got = model.generate(enc, [prompt] * 3, return_scores=True, return_no_speech_prob=True, **kw)
+                out.append([(g.sequences_ids, [np.float32(s).tobytes() for s in g.scores],
+                             np.float32(g.no_speech_prob).tobytes()) for g in got])
+            enc2 = model.encode(StorageView.from_array(feats))          # align fills a block of its own
+            al = model.align(enc2, cfg.sot_sequence, text, [3000, 1250, 2000], median_filter_width=7)
+            out.append([(a.alignments, np.asarray(a.text_token_probs, np.float32).tobytes()) for a in al])
+            if cfg.is_multilingual:
+                enc3 = model.encode(StorageView.from_array(feats))
+                out.append(model.detect_language(enc3))
+            res[on] = out
+    finally:
+        _lib.check(lib.fw_test_knob(6, 1))
+    for i, (a, b) in enumerate(zip(res[0], res[1])):
+        assert a == b, f"layered cross-K/V projection changed result set {i}"
+    print(f"[{cfg.name}] cross-K/V projections per layer / layered: identical ids, scores, no-speech, alignments, languages")
+
+
 def test_position_blocks_same_bits(setup):
     """Round 5 (fw_test_knob 4, default on): the prompt forward of `generate` and the teacher-forced pass of `align` go
     through the decoder in blocks of up to 16 positions per pass (rows = chunks x positions; a sibling position's K / V
