@@ -496,11 +496,19 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             rows_per_run = args.beam * (ps1["chunks"] - ps0["chunks"]) / max(1, ps1["runs"] - ps0["runs"])
             # runs of at least DEC_BIG_MIN_ROWS rows take the GEMM-shaped kernel (dec_gemm_big_kernel) and are priced against
             # the MFMA roof; below it the linears are weight-streaming launches priced against HBM
-            big_rows = model.dec_big_min_rows() if hasattr(model, "dec_big_min_rows") else 1024
-            gemm_shaped = rows_per_run >= big_rows
+            # (every linear has its own measured crossover: include/fwamd_test.h fw_dec_big_min_rows_of; a family is priced
+            #  against the MFMA roof only when ITS kernel of the profiled round was the GEMM-shaped one)
+            roles = {"dec_gemm_qkv": 0, "dec_gemm_dxd": 1, "dec_gemm_ffn1": 2, "dec_gemm_ffn2": 3}
+            if hasattr(model, "dec_big_min_rows_of"):
+                big_of = {k: model.dec_big_min_rows_of(r) for k, r in roles.items()}
+            else:
+                big_of = {k: (model.dec_big_min_rows() if hasattr(model, "dec_big_min_rows") else 1024) for k in roles}
+            shaped = {k: rows_per_run >= v for k, v in big_of.items()}
+            gemm_shaped = all(shaped.values())          # "dec_gemm" as a whole: every linear took the GEMM-shaped kernel
+            big_rows = max(big_of.values())
 
             def roof_of(name, v):
-                if name in MFMA_FAMILIES or (name == "dec_gemm" and gemm_shaped):
+                if name in MFMA_FAMILIES or (name == "dec_gemm" and gemm_shaped) or shaped.get(name, False):
                     ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
                     return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
@@ -526,18 +534,28 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                               "and a kernel's wall time is no longer its own)")
             parts = [v for k, v in rep.items() if k.startswith("dec_gemm_")]
             others = {}
-            if parts:
+            mixed = any(shaped.values()) and not gemm_shaped
+            if parts and not mixed:
                 others["dec_gemm"] = {f: sum(v[f] for v in parts) for f in ("ms", "bytes", "flops", "launches")}
+            elif parts:                     # some linears on either kernel: one entry per role, each with its own bound
+                for k in roles:
+                    if k in rep:
+                        others[k] = rep[k]
             for k in ("enc_gemm", "dec_cross_attn", "dec_self_attn", "enc_attn"):
                 if k in rep and k != name:
                     others[k] = rep[k]
             out["roofline_others"] = {
                 k: dict(roof_of(k, v), kernel_ms_per_step=round(v["ms"], 3),
-                        traffic=(pmc_traffic(k, gemm_shaped) or {}).get("hbm_read_bytes_per_launch"),
-                        traffic_kernel=(pmc_traffic(k, gemm_shaped) or {}).get("kernel"))
+                        traffic=(pmc_traffic(k, gemm_shaped or shaped.get(k, False)) or {}).get("hbm_read_bytes_per_launch"),
+                        traffic_kernel=(pmc_traffic(k, gemm_shaped or shaped.get(k, False)) or {}).get("kernel"))
                 for k, v in others.items()
-                if v["ms"] > 0 and (v["flops"] > 0 if (k in MFMA_FAMILIES or (k == "dec_gemm" and gemm_shaped))
-                                    else v["bytes"] > 0)}
+                if v["ms"] > 0 and (v["flops"] > 0 if (k in MFMA_FAMILIES or (k == "dec_gemm" and gemm_shaped)
+                                                     or shaped.get(k, False)) else v["bytes"] > 0)}
+            if mixed:
+                out["roofline_others_note"] = (
+                    f"decode runs of {rows_per_run:.0f} rows on average: the linears switch to dec_gemm_big_kernel at "
+                    f"{big_of} rows, so the four role families are listed one by one, each against the roof of the kernel "
+                    "that served it")
             if "dec_gemm" in out["roofline_others"]:
                 out["roofline_others"]["dec_gemm"]["note"] = (
                     f"decode runs of {rows_per_run:.0f} rows on average (>= {big_rows}: dec_gemm_big_kernel): the six per-layer "
@@ -564,7 +582,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
         # ---- CPU baseline: the oracle (torch fp32 port) on a bounded sample of the same workload ----
         # (reported at N = 1 only: at N > 1 the other ranks would idle at the final barrier while it runs)
         if not args.no_cpu_baseline and not multi:
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks[0], prompt, args.beam, L, gen_kw(L))
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, chunks, prompt, args.beam, L, gen_kw(L))
         print(json.dumps(out), flush=True)
     for st_ in staged_sets:
         model.free_staged(st_)
@@ -627,7 +645,7 @@ def one_batch(model, staged, chunks, prompt, kw, L, batch, reps=4):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-PMC_TAGS = ("r05", "r04")                 # the round's counter passes (profiles/collect.sh <tag>), newest first:
+PMC_TAGS = ("r06", "r05", "r04")                 # the round's counter passes (profiles/collect.sh <tag>), newest first:
 #   <tag>_pmc_fetch_w32.json   the TIMED configuration (32 workers, merged decode runs, one lane)
 #   <tag>_pmc_fetch.json       one 16-chunk batch per decode run
 _PMC_KERNEL = {"dec_cross_attn": "dec_cross_attn_kernel", "enc_gemm": "gemm_f16", "enc_attn": "attn_enc_kernel",
@@ -648,9 +666,10 @@ def pmc_traffic(family, gemm_shaped=False):
     correction already applied by profiles/parse_pmc.py; null if the kernel was not measured.  gemm_shaped: the decoder
     linears of the profiled round took dec_gemm_big_kernel (runs >= fw_dec_big_min_rows rows) — its figure, not the
     register-streaming kernel's."""
-    if family not in _PMC_KERNEL:
+    fam0 = "dec_gemm" if family.startswith("dec_gemm") else family
+    if fam0 not in _PMC_KERNEL:
         return None
-    kernel = "dec_gemm_big_kernel" if (family == "dec_gemm" and gemm_shaped) else _PMC_KERNEL[family]
+    kernel = "dec_gemm_big_kernel" if (fam0 == "dec_gemm" and gemm_shaped) else _PMC_KERNEL[fam0]
     for suffix, what in (("fetch_w32", "the counter pass of the timed configuration (profiles/collect.sh: the bench command "
                                        "with 32 workers, one decode lane, eager decode step: merged decode runs)"),
                          ("fetch", "the counter pass with --workers 1 (one 16-chunk batch per decode run, eager decode step)")):
@@ -682,9 +701,18 @@ def pmc_traffic(family, gemm_shaped=False):
     return None
 
 
-def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
-    """oracle/ (CPU restatement, torch fp32) on a BOUNDED sample of the same workload, one 30 s chunk: log-mel, the whole
-    encoder, cross-K/V + prompt — all measured — and 8 beam steps, extrapolated linearly to L steps (about 20 s of CPU)."""
+def cpu_baseline(cfg, weights, chunks, prompt, beam, L, gen_kw):
+    """oracle/ (CPU restatement, torch fp32) on a BOUNDED sample of the same workload — per 30 s chunk: log-mel, the whole
+    encoder, cross-K/V + prompt (all measured) and 8 beam steps, extrapolated linearly to L steps.
+
+    Two figures (round 6, verdict item 6: "timed on the host cores of the same box"):
+      * `value`: ALL host cores — host_cores // 32 concurrent streams of 32 threads each (the oracle decodes one chunk at a
+        time, and a 32-thread team is where its matmuls stop scaling: the way CTranslate2 would be run on this box is
+        inter_threads x intra_threads), each on its own chunk of the batch, sharing one copy of the weights; the streams run
+        the sample side by side (so they contend for memory bandwidth as a real run would) and the figure is the SUM of
+        their rates.  `cores` = the threads actually used.
+      * `one_stream`: one chunk on 32 threads alone (what rounds 1-5 reported as the baseline)."""
+    import threading
     import torch
     from oracle import logmel as olm
     from oracle.whisper import OracleWhisper
@@ -692,37 +720,77 @@ def cpu_baseline(cfg, weights, chunk, prompt, beam, L, gen_kw):
         from faster_whisper_amd import synthetic_weights
         weights = synthetic_weights(cfg, seed=1234)
     host_cores = os.cpu_count() or 1
-    cores = min(host_cores, 32)   # more threads only add synchronisation cost at these sizes
-    torch.set_num_threads(cores)
+    team = min(host_cores, 32)    # more threads per matmul only add synchronisation cost at these sizes
+    if os.environ.get("FWAMD_CPU_BASELINE_TEAM"):          # (test seam: several streams on a small host)
+        team = max(1, min(host_cores, int(os.environ["FWAMD_CPU_BASELINE_TEAM"])))
+    torch.set_num_threads(team)
     oracle = OracleWhisper(cfg, weights, emulate_fp16=False)
+    n_meas = 8
 
     def timed(fn):
         t0 = time.perf_counter()
         r = fn()
         return r, time.perf_counter() - t0
 
-    feats, t_mel = timed(lambda: olm.log_mel_chunks([chunk], cfg.n_mels))
-    enc, t_enc = timed(lambda: oracle.encode(feats))             # the whole encoder of one chunk, measured
-    kw = dict(gen_kw)
-    kw.pop("return_scores", None)
-    kw.pop("return_no_speech_prob", None)
+    def sample(chunk):
+        feats, t_mel = timed(lambda: olm.log_mel_chunks([chunk], cfg.n_mels))
+        enc, t_enc = timed(lambda: oracle.encode(feats))             # the whole encoder of one chunk, measured
+        kw = dict(gen_kw)
+        kw.pop("return_scores", None)
+        kw.pop("return_no_speech_prob", None)
 
-    def gen(n):
-        kw["max_length"] = len(prompt) + n
-        kw["min_new_tokens"] = n
-        return timed(lambda: oracle.generate(enc, [prompt], **kw))[1]
+        def gen(n):
+            kw["max_length"] = len(prompt) + n
+            kw["min_new_tokens"] = n
+            return timed(lambda: oracle.generate(enc, [prompt], **kw))[1]
 
-    n_meas = 8
-    t1, tn = gen(1), gen(1 + n_meas)
-    per_step = max(1e-6, (tn - t1) / n_meas)
-    fixed = max(0.0, t1 - per_step)              # cross-K/V projection + prompt forward
-    total = t_mel + t_enc + fixed + per_step * L
-    return {"value": round(30.0 / total, 4), "unit": "audio-seconds per wall-second", "cores": cores,
-            "host_cores": host_cores, "kind": "port", "oracle_sha16": oracle_rev(),
-            "sample": f"1 chunk (30 s): numpy log-mel {t_mel:.2f}s; the whole encoder measured {t_enc:.1f}s; cross-KV+prompt "
-                      f"{fixed:.2f}s; {n_meas} beam-{beam} steps measured ({per_step * 1e3:.0f} ms/step) -> {L} steps "
-                      f"(a step's cost does not depend on its index: KV-cached); torch fp32 restatement (oracle/) on {cores} "
-                      f"of the box's {host_cores} hardware threads, not CTranslate2 (absent offline: BASELINE.md section 3)"}
+        t1, tn = gen(1), gen(1 + n_meas)
+        per_step = max(1e-6, (tn - t1) / n_meas)
+        fixed = max(0.0, t1 - per_step)              # cross-K/V projection + prompt forward
+        return {"t_mel": t_mel, "t_enc": t_enc, "fixed": fixed, "per_step": per_step,
+                "total": t_mel + t_enc + fixed + per_step * L}
+
+    one = sample(chunks[0])
+
+    def describe(r):
+        return (f"numpy log-mel {r['t_mel']:.2f}s; the whole encoder measured {r['t_enc']:.1f}s; cross-KV+prompt "
+                f"{r['fixed']:.2f}s; {n_meas} beam-{beam} steps measured ({r['per_step'] * 1e3:.0f} ms/step) -> {L} steps")
+
+    out = {"value": round(30.0 / one["total"], 4), "unit": "audio-seconds per wall-second", "cores": team,
+           "host_cores": host_cores, "kind": "port", "oracle_sha16": oracle_rev(),
+           "one_stream": {"value": round(30.0 / one["total"], 4), "cores": team,
+                          "sample": "1 chunk (30 s) alone on the box: " + describe(one)}}
+    streams = host_cores // team
+    if streams > 1:
+        res = [None] * streams
+        go = threading.Barrier(streams)
+
+        def work(i):
+            torch.set_num_threads(team)          # (per calling thread: every stream runs its own team)
+            go.wait()
+            res[i] = sample(chunks[i % len(chunks)])
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(streams)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - t0
+        if all(r is not None for r in res):
+            out["value"] = round(sum(30.0 / r["total"] for r in res), 4)
+            out["cores"] = streams * team
+            slow = max(res, key=lambda r: r["total"])
+            out["all_cores"] = {"streams": streams, "threads_per_stream": team, "sample_wall_s": round(wall, 1),
+                                "per_stream_value": [round(30.0 / r["total"], 4) for r in res],
+                                "slowest_stream": describe(slow)}
+    out["sample"] = (f"{out['cores'] // team} concurrent stream(s) x {team} threads, one 30 s chunk of the batch each (the oracle "
+                     f"decodes chunk by chunk), sum of the streams' rates; per stream: log-mel + the whole encoder + cross-KV + "
+                     f"prompt measured, {n_meas} beam-{beam} steps measured and extrapolated to {L} (a step's cost does not "
+                     f"depend on its index: KV-cached); one stream alone: {describe(one)}; torch fp32 restatement (oracle/) on "
+                     f"{out['cores']} of the box's {host_cores} hardware threads, not CTranslate2 (absent offline: BASELINE.md "
+                     "section 3)")
+    return out
 
 
 if __name__ == "__main__":

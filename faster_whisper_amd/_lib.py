@@ -15,6 +15,7 @@ FW_EINVAL = -1
 FW_ENODEV = -2
 FW_ENOMEM = -3
 FW_ERUNTIME = -4
+FW_ENOSPC = -5
 
 COMPUTE_FLOAT16 = 0
 COMPUTE_INT8_FLOAT16 = 1
@@ -67,7 +68,7 @@ SYMBOLS = [
     "fw_last_error", "fw_abi_version", "fw_device_count",
     "fw_model_create", "fw_model_free", "fw_model_info", "fw_model_blob", "fw_model_create_from_blob_dev",
     "fw_model_set_decode_batch", "fw_model_decode_batch", "fw_model_join_decoder", "fw_model_decode_stats",
-    "fw_model_set_merge_wait", "fw_model_set_decode_lanes", "fw_model_run_capacity", "fw_dec_big_min_rows", "fw_test_knob",
+    "fw_model_set_merge_wait", "fw_model_set_decode_lanes", "fw_model_run_capacity", "fw_dec_big_min_rows", "fw_dec_big_min_rows_of", "fw_test_knob",
     "fw_test_idle_lead_chunks",
     "fw_pack_blob_size", "fw_pack_blob_copy", "fw_pack_blob_free",
     "fw_logmel", "fw_logmel_full",
@@ -115,6 +116,8 @@ def load():
     lib.fw_model_run_capacity.argtypes = [vp]
     lib.fw_model_run_capacity.restype = i32
     lib.fw_dec_big_min_rows.restype = i32
+    lib.fw_dec_big_min_rows_of.restype = i32
+    lib.fw_dec_big_min_rows_of.argtypes = [i32, i32]
     if hasattr(lib, "fw_flac_info"):
         lib.fw_flac_info.argtypes = [vp, i64, i32p, i32p, i32p, i64p]
         lib.fw_flac_decode.argtypes = [vp, i64, vp, i64, i64p, i32p]
@@ -179,7 +182,7 @@ def check(rc: int):
     if rc == FW_OK:
         return
     msg = load().fw_last_error().decode("utf-8", "replace")
-    if rc == FW_EINVAL:
+    if rc in (FW_EINVAL, FW_ENOSPC):      # (a too-small caller buffer is a bad argument of that call)
         raise ValueError(msg)
     raise RuntimeError(f"libfwamd error {rc}: {msg}")
 

@@ -13,6 +13,7 @@ the reference decodes with PyAV (bundled FFmpeg), resamples to signed 16-bit at 
 `pad_or_trim` (audio.py:111-123) lives in transcribe.py.
 """
 import io
+import os
 import struct
 from math import gcd
 from typing import BinaryIO, Tuple, Union
@@ -64,8 +65,15 @@ def _read_wav(data: bytes) -> Tuple[np.ndarray, int]:
     return x[:n * channels].reshape(n, channels), rate
 
 
+def max_decoded_seconds() -> float:
+    """ceiling on the audio one file may decode to (FWAMD_MAX_AUDIO_SECONDS, default 48 h): a FLAC stream of CONSTANT
+    subframes codes 65 535 samples per channel in ~11 bytes, so a small crafted file could otherwise ask for tens of GB"""
+    return float(os.environ.get("FWAMD_MAX_AUDIO_SECONDS", 48 * 3600))
+
+
 def _read_flac(data: bytes) -> Tuple[np.ndarray, int]:
-    """-> (float32 [frames, channels] in [-1, 1), sample rate); raises ValueError on a corrupt stream (CRC / MD5)"""
+    """-> (float32 [frames, channels] in [-1, 1), sample rate); raises ValueError on a corrupt stream (CRC / MD5) and on a
+    stream that decodes to more than max_decoded_seconds() of audio"""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -77,15 +85,24 @@ def _read_flac(data: bytes) -> Tuple[np.ndarray, int]:
     # start from what the data plausibly holds and grow on "too small" up to the format's own ceiling for this many
     # bytes (a frame is at least 11 bytes: header, one subframe byte per channel, CRC-16).
     hard_cap = (len(data) // 11 + 1) * 65535
+    limit = int(max_decoded_seconds() * max(1, rate.value))
+    if 0 < total.value <= hard_cap and total.value > limit:
+        raise ValueError(f"FLAC: the stream announces {total.value / max(1, rate.value):.0f} s of audio, more than the "
+                         f"{max_decoded_seconds():.0f} s this front end decodes (FWAMD_MAX_AUDIO_SECONDS)")
     want = min(total.value, hard_cap) if total.value > 0 else hard_cap
+    bounded = want > limit           # (only an unannounced / implausible length gets here with want > limit)
+    want = min(want, limit)
     cap = max(1, min(want, 16 * len(data)))
     n, md5 = C.c_int64(), C.c_int32()
     while True:
         out = np.zeros((cap, ch.value), dtype=np.int32)
         rc = lib.fw_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(md5))
-        if rc != 0 and cap < want and b"too small" in (lib.fw_last_error() or b""):
+        if rc == _lib.FW_ENOSPC and cap < want:
             cap = min(want, cap * 4)
             continue
+        if rc == _lib.FW_ENOSPC and bounded:
+            raise ValueError(f"FLAC: the stream decodes to more than {max_decoded_seconds():.0f} s of audio "
+                             "(FWAMD_MAX_AUDIO_SECONDS): refusing to allocate for it")
         _lib.check(rc)
         break
     if 0 < total.value != n.value:

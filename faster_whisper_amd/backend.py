@@ -332,6 +332,11 @@ class Whisper:
         """rows from which a decode run's linears take the GEMM-shaped kernel (bench.py prices them accordingly)"""
         return int(self._lib.fw_dec_big_min_rows())
 
+    def dec_big_min_rows_of(self, role: int) -> int:
+        """the same for one linear (0 qkv, 1 d x d, 2 ffn1, 3 ffn2) of THIS model's compute type: every linear has its own
+        measured crossover (include/fwamd_test.h)"""
+        return int(self._lib.fw_dec_big_min_rows_of(int(role), 1 if self._compute_type_name == "int8_float16" else 0))
+
     def _replica_for(self, features: Optional[StorageView]) -> _Replica:
         if features is not None and features._owner is not None:
             return features._owner

@@ -45,6 +45,7 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
                        int kmul, half_t* out, int B, int H, const int* done, int kv_div, int frag, const int* slot_map);
 // rows from which launch_dec_gemm_frag hands a decode run's linears to the GEMM-shaped kernel
 int dec_big_min_rows();
+int dec_big_min_rows_of(int role, int compute_type);   // role 0 qkv, 1 d x d, 2 ffn1, 3 ffn2, < 0: the lowest; 0 fp16 / 1 int8
 // frag = 1: `out` is a fragment-major [rows/16][d/32][64][8] buffer (input of launch_dec_gemm_frag)
 int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                          const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,

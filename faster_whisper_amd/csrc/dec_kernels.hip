@@ -14,6 +14,7 @@
 #include "dec_kernels.h"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace fwd {
 static std::atomic<int> g_self_attn_form{0};   // fw_test_knob(2, ..): A/B of the self-attention forms
@@ -323,7 +324,7 @@ static __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("" ::: "memory");         \
   } while (0)
 
-template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
+template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST, bool STG = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
@@ -447,31 +448,111 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     }
   };
 
+  if constexpr (STG) {
+    // ---- round 6: two STAGGERED wave groups (waves w and w + 4 share a SIMD; group = wave >> 2) ----
+    // The lockstep loop below serialises, on every SIMD, [both waves blocked in their global_load_lds issues: the CU's
+    // L2 -> LDS path takes ~28 cycles per 1 KB piece whoever issues it] and [both waves' MFMAs].  Here a k-step is two
+    // half-phases separated by barriers A and B; in each, one group ISSUES its share of the stage LEAD k-steps ahead
+    // while the other group MULTIPLIES, so a wave's DMA issue time runs beside its SIMD partner's MFMAs (the structure
+    // of gemm.hip's K loop).  Group 1 runs one multiply behind group 0:
+    //     group 0, k-step c:  A(c) | issue(c + LEAD), wait own pieces of c | B(c) | multiply(c)
+    //     group 1, k-step c:  A(c) | multiply(c - 1), wait own pieces of c | B(c) | issue(c + LEAD)
+    //   RAW: stage c is complete for everybody at B(c) (both groups' counted waits precede it); group 1 reads it after
+    //        A(c + 1) > B(c).   WAR: stage c + LEAD lands in the slot of stage c + LEAD - NST = c - 2 (LEAD = NST - 2),
+    //        last read by group 1 between A(c - 1) and B(c - 1) and by group 0 before A(c - 1): both before A(c).
+    // Same MFMA chains per wave, same slice order, same epilogue as the lockstep form: the same bits.
+    static_assert(NW == 8 && KC == 1 && NST >= 5, "staggered form: 8 waves, one k-step per stage, ring of >= 5");
+    constexpr int LEAD = NST - 2;
+    const int grp = wave >> 2;
 #pragma unroll
-  for (int c0 = 0; c0 < NST - 1; ++c0) issue(c0, c0);
-  int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
-  int to_slice = ch_per_slice;
-  const int n_steady = nch - (NST - 1);
-  // steady state: stages c .. c + NST - 2 are in flight; wait until only the NST - 2 younger ones are
-  for (int c = 0; c < n_steady; ++c) {
-    wait_vmcnt<(NST - 2) * PPW>();
-    DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
-    issue(c + NST - 1, fill);             // ... whose slot is the one refilled now
-    compute(slot);
-    if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-    fill = slot;
-    slot = (slot + 1 == NST) ? 0 : slot + 1;
+    for (int c0 = 0; c0 < LEAD; ++c0) issue(c0, c0);
+    int to_slice = ch_per_slice;
+    const int n_steady = nch - LEAD;          // k-steps that still issue (the launcher guarantees nch >= NST)
+    auto next = [](int sl) { return (sl + 1 == NST) ? 0 : sl + 1; };
+    if (grp == 0) {
+      int slot = 0, fill = LEAD;
+      for (int c = 0; c < n_steady; ++c) {
+        DGB_BARRIER();                        // A(c)
+        issue(c + LEAD, fill);
+        wait_vmcnt<LEAD * PPW>();             // own pieces of stage c (LEAD younger stages stay in flight)
+        DGB_BARRIER();                        // B(c)
+        compute(slot);
+        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+        slot = next(slot); fill = next(fill);
+      }
+      auto tail0 = [&](auto jc) {             // k-step n_steady + j: nothing left to issue
+        constexpr int j = decltype(jc)::value;
+        DGB_BARRIER();
+        wait_vmcnt<(LEAD - 1 - j) * PPW>();
+        DGB_BARRIER();
+        compute(slot);
+        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+        slot = next(slot);
+      };
+      tail0(std::integral_constant<int, 0>{});
+      tail0(std::integral_constant<int, 1>{});
+      tail0(std::integral_constant<int, 2>{});
+      if constexpr (LEAD > 3) tail0(std::integral_constant<int, 3>{});
+    } else {
+      int slot = 0, fill = LEAD;              // slot: the stage group 1 multiplies next (one behind group 0)
+      DGB_BARRIER();                          // A(0): nothing to multiply yet
+      wait_vmcnt<(LEAD - 1) * PPW>();
+      DGB_BARRIER();                          // B(0)
+      issue(LEAD, fill);
+      fill = next(fill);
+      for (int c = 1; c < n_steady; ++c) {
+        DGB_BARRIER();                        // A(c)
+        compute(slot);                        // stage c - 1
+        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+        wait_vmcnt<(LEAD - 1) * PPW>();       // own pieces of stage c
+        DGB_BARRIER();                        // B(c)
+        issue(c + LEAD, fill);
+        slot = next(slot); fill = next(fill);
+      }
+      auto tail1 = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        DGB_BARRIER();
+        compute(slot);
+        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+        slot = next(slot);
+        wait_vmcnt<(LEAD - 1 - j) * PPW>();
+        DGB_BARRIER();
+      };
+      tail1(std::integral_constant<int, 0>{});
+      tail1(std::integral_constant<int, 1>{});
+      tail1(std::integral_constant<int, 2>{});
+      if constexpr (LEAD > 3) tail1(std::integral_constant<int, 3>{});
+      compute(slot);                          // the last stage, beside group 0's wait at the barrier below
+      if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+    }
+    DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
+  } else {
+#pragma unroll
+    for (int c0 = 0; c0 < NST - 1; ++c0) issue(c0, c0);
+    int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
+    int to_slice = ch_per_slice;
+    const int n_steady = nch - (NST - 1);
+    // steady state: stages c .. c + NST - 2 are in flight; wait until only the NST - 2 younger ones are
+    for (int c = 0; c < n_steady; ++c) {
+      wait_vmcnt<(NST - 2) * PPW>();
+      DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
+      issue(c + NST - 1, fill);             // ... whose slot is the one refilled now
+      compute(slot);
+      if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+      fill = slot;
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+    }
+    // tail: nothing left to issue; the queue is drained once
+    wait_vmcnt<0>();
+  #pragma unroll 1
+    for (int c = n_steady; c < nch; ++c) {
+      DGB_BARRIER();
+      compute(slot);
+      if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+    }
+    DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
   }
-  // tail: nothing left to issue; the queue is drained once
-  wait_vmcnt<0>();
-#pragma unroll 1
-  for (int c = n_steady; c < nch; ++c) {
-    DGB_BARRIER();
-    compute(slot);
-    if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-    slot = (slot + 1 == NST) ? 0 : slot + 1;
-  }
-  DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
 
   // ---------------------------------- epilogue ----------------------------------
   char* ep = dgb_smem + wave * (64 * DGB_EP_STRIDE);       // this wave's 64-row x (16 FB)-column patch, fp16
@@ -1688,7 +1769,7 @@ namespace fwd {
 
 // row count from which the decoder linears of a decode run take the LDS-staged GEMM-shaped kernel
 // (profiles/r03_dec_linear_bench.txt)
-#define DEC_BIG_MIN_ROWS 704   /* the lowest of the per-linear crossovers (launch_dec_gemm_frag) */
+// (per linear: DEC_BIG_RULES below)
 
 void launch_embed(hipStream_t st, const int* tok, const half_t* emb, const half_t* pos_emb, half_t* x, half_t* xfrag,
                   int rows, int d, const int* d_step, int pos_fixed, int P, int blk_n) {
@@ -1714,9 +1795,11 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
 //          workgroups per CU) — the linears with 1280 columns (out / cross-q / cross-out, ffn2), which a wider tile
 //          cannot spread over the chip
 //   cfg 2: 2 x 2 waves, 128 x 128, 1 k-step per stage, 4 stages (64 KB)
+//   cfg 3: cfg 0's tile with two STAGGERED wave groups, 1 k-step per stage, ring of 6 (144 KB), 4 k-steps in flight (round 6)
+//   cfg 4: the same with a ring of 5 (120 KB), 3 k-steps in flight
 // (measured next to 256 x 64, 128 x 256, 8 waves on 128 x 128, deeper rings, two k-steps per barrier, LDS reads
 //  software-pipelined under the MFMAs, L2 touch-ahead: profiles/r03_dec_linear_bench.txt — none better)
-template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
+template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST, bool STG>
 static int big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
   constexpr int lds = (4 * WM + FB * WN) * KC * 1024 * NST;
@@ -1726,17 +1809,17 @@ static int big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST, STG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -1;
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int nMt = ((R + 15) / 16 + 4 * WM - 1) / (4 * WM), nNt = (N / 16 + FB * WN - 1) / (FB * WN);
-  dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out, ldo,
-                                                                                      out_frag, R, N, K, act, nNt);
+  dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST, STG><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out,
+                                                                                           ldo, out_frag, R, N, K, act, nNt);
   return hipPeekAtLastError() == hipSuccess ? 0 : -1;
 }
-template <int WM, int WN, int FB, int KC, int NST>
+template <int WM, int WN, int FB, int KC, int NST, bool STG = false>
 static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
   if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
@@ -1744,7 +1827,7 @@ static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const hal
   const int KS = K / 32;
   if (KS % S != 0 || (KS / S) % KC != 0 || KS / KC < NST) return -1;
   if ((ldo % 8) || (res && (ldr % 8))) return -1;   // 16-byte row segments
-#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, FB, KC, NST>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
+#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, FB, KC, NST, STG>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
   if (s1) return S == 8 ? DGB(true, 8) : DGB(true, 4);
   return S == 8 ? DGB(false, 8) : DGB(false, 4);
 #undef DGB
@@ -1756,6 +1839,8 @@ int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t*
     case 0: return big_cfg<4, 2, 4, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 1: return big_cfg<2, 2, 2, 1, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 2: return big_cfg<2, 2, 4, 1, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 3: return big_cfg<4, 2, 4, 1, 6, true>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 4: return big_cfg<4, 2, 4, 1, 5, true>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     default: return -1;
   }
 }
@@ -1793,12 +1878,42 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 26: frag_variant<8, 1, 2, 6>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 21: frag_variant<4, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 22: frag_variant<8, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
-    case 10: case 11: case 12:
+    case 10: case 11: case 12: case 13: case 14:
       return launch_dec_gemm_big(st, variant - 10, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr,
                                  nullptr, 0, out, N, nullptr, R, N, K, 0);
     default: return -1;
   }
   return 0;
+}
+
+// Which linear of a decoder layer a shape is: 0 qkv (N = 3 K), 1 d x d (out / cross-q / cross-out), 2 ffn1, 3 ffn2.
+static int dec_linear_role(int N, int K) { return N == 3 * K ? 0 : (N >= 2560 ? 2 : (K >= 2560 ? 3 : 1)); }
+// Row counts from which each linear of a decode run takes the LDS-staged GEMM-shaped kernel, and the workgroup shape it
+// takes there (launch_dec_gemm_big's cfg) — ONE table: the launcher below, fw_dec_big_min_rows_of (the benchmark prices a
+// linear against the MFMA roof only from ITS row count on) and the tests read it.  Measured crossovers:
+// profiles/r05_dec_linear_bench_call1.txt (round 5), profiles/r06_dec_linear_bench_*.txt (round 6: staggered 256 x 128).
+struct DecBigRule { int rows; int cfg; };
+static const DecBigRule DEC_BIG_RULES[4][2] = {
+    /* qkv  */ {{704, 2}, {1280, 0}},
+    /* dxd  */ {{1120, 1}, {1 << 30, 1}},
+    /* ffn1 */ {{864, 0}, {1 << 30, 0}},
+    /* ffn2 */ {{896, 1}, {1 << 30, 1}},
+};
+static int dec_big_cfg_for(int R, int N, int K) {
+  const DecBigRule* r = DEC_BIG_RULES[dec_linear_role(N, K)];
+  if (R >= r[1].rows) return r[1].cfg;
+  if (R >= r[0].rows) return r[0].cfg;
+  return -1;
+}
+// role 0..3 as above; compute_type 0 float16, 1 int8_float16 (launch_dec_gemm_frag_i8: the 4 x 4-tile form from
+// DEC_BIG_MIN_ROWS_I8 rows for every linear); role < 0: the lowest row count of any linear
+#define DEC_BIG_MIN_ROWS_I8 1024
+int dec_big_min_rows_of(int role, int compute_type) {
+  if (compute_type == 1) return DEC_BIG_MIN_ROWS_I8;
+  if (role >= 0 && role < 4) return DEC_BIG_RULES[role][0].rows;
+  int lo = DEC_BIG_RULES[0][0].rows;
+  for (int k = 1; k < 4; ++k) lo = DEC_BIG_RULES[k][0].rows < lo ? DEC_BIG_RULES[k][0].rows : lo;
+  return lo;
 }
 
 static bool skinny_one_tile(int R, int N) { return R <= 16 || (R <= 96 && N <= 1280); }
@@ -1819,20 +1934,14 @@ int launch_dec_gemm_frag(hipStream_t st, const half_t* xf, const half_t* Wf, con
   // 1 280 rows), ffn1 34.4 / 40.0 / 45.0 vs 34.9 / 35.3 / 37.3 (256 x 128), ffn2 33.0 / 39.1 / 45.1 vs 35.8 / 35.9 / 36.6
   // (128 x 64), d x d 10.1 / 11.9 / 13.2 vs 12.8 / 13.0 / 13.1 (128 x 64): the fixed ~12-35 us of an LDS-staged launch
   // (its K loop's latency) is reached at a different row count by each shape.  Same bits from every form.
-  int cfg = -1;
-  if (N >= 2560) {
-    if (N == 3 * K) cfg = R >= 1280 ? 0 : (R >= 704 ? 2 : -1);                       // qkv (N = 3 d)
-    else cfg = R >= 864 ? 0 : -1;                                                    // ffn1 (N = 4 d)
-  } else {
-    cfg = (K >= 2560 ? R >= 896 : R >= 1120) ? 1 : -1;                               // ffn2 (K = 4 d) / d x d
-  }
-  if (cfg >= 0 && R >= DEC_BIG_MIN_ROWS &&
+  const int cfg = dec_big_cfg_for(R, N, K);
+  if (cfg >= 0 &&
       launch_dec_gemm_big(st, cfg, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act) == 0)
     return 0;
   return launch_dec_gemm_skinny(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
 }
 
-int dec_big_min_rows() { return DEC_BIG_MIN_ROWS; }
+int dec_big_min_rows() { return dec_big_min_rows_of(-1, 0); }
 
 int launch_dec_gemm_skinny(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1,
                            const float* cf, const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R,
@@ -1878,7 +1987,7 @@ int launch_dec_gemm_frag_i8(hipStream_t st, const int8_t* xq, const float* x_sca
                             const float* w_scale, const half_t* bias, const half_t* res, int ldr, half_t* out, int ldo,
                             int R, int N, int K, int act) {
   if (K % 64 != 0 || N % 32 != 0 || R < 1 || !x_scale || !w_scale) return -1;
-  if (R >= 1024 && N % 64 == 0) {   // (measured crossover of the int8 forms)
+  if (R >= DEC_BIG_MIN_ROWS_I8 && N % 64 == 0) {   // (measured crossover of the int8 forms)
     // merged runs: 4 x 4 tiles per workgroup, a quarter of the operand traffic per output (the fp16 form of this grouping
     // measured 216 -> 174 us per layer at 1 520 rows); integer accumulation: the result does not depend on the grouping
     const dim3 g4(N / 64, ((R + 15) / 16 + 3) / 4);

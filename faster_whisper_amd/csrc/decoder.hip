@@ -241,7 +241,7 @@ static int gen_workspace_build(Model* m) {
   (void)B;
   FW_CHECK_ARG(R <= 2048, "decode_batch * max_beam must be <= 2048 (got %zu)", R);
   FW_HIP(hipSetDevice(m->device));
-  if (!m->dec_stream) FW_HIP(create_stream(&m->dec_stream, "FWAMD_DEC_STREAM_PRIO"));
+  if (!m->dec_stream) FW_HIP(create_stream(&m->dec_stream, "DEC"));
   int rc;
 #define A(p, n) do { if ((rc = dev_alloc_t(&(p), (n)))) return rc; } while (0)
   A(g->slot_map, R);

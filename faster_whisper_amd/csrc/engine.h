@@ -230,7 +230,7 @@ int dev_alloc(void** p, size_t bytes);
 // the default priority).  ROCm gives every priority level its own hardware queues, so a decode stream created "high"
 // neither shares a hardware queue with the encoder streams of the workers nor waits behind their workgroups when a CU
 // frees up.  Measurement knob: FWAMD_DEC_STREAM_PRIO (decode lanes), FWAMD_ENC_STREAM_PRIO (encoder / replica streams).
-hipError_t create_stream(hipStream_t* st, const char* env);
+hipError_t create_stream(hipStream_t* st, const char* role);   // role "ENC" / "DEC": engine.hip
 // decode groups (decoder.hip): chunks an idle two-lane group waits for before it leads a run
 int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch);
 template <typename T>

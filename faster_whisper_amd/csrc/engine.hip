@@ -720,7 +720,7 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
     m->tensors[e.name] = t;
   }
   auto fail = [&](int code) { fw_model_free(fm); return code; };
-  hipError_t he = create_stream(&m->stream, decoder_lane ? "FWAMD_DEC_STREAM_PRIO" : "FWAMD_ENC_STREAM_PRIO");
+  hipError_t he = create_stream(&m->stream, decoder_lane ? "DEC" : "ENC");
   if (he != hipSuccess) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
     return fail(FW_ENODEV);
@@ -760,8 +760,40 @@ static int model_from_blob(const void* blob_dev, int64_t blob_bytes, bool owned,
   return FW_OK;
 }
 
-hipError_t create_stream(hipStream_t* st, const char* env) {
-  const char* e = env ? getenv(env) : nullptr;
+// CU mask of n CUs (a multiple of 32), the same number in every XCD.  Whether bit i of a HIP CU mask is CU (i / 8) of XCD
+// (i % 8) — the order the KFD documents for multi-XCC parts — or CU (i % 32) of XCD (i / 32) does not matter here: with
+// a = i % 8, b = i / 8 the rule (a + b) % 8 < n / 32 selects n / 8 CUs of every XCD under either reading (for a fixed a the
+// 32 values of b hit every residue four times; for the four b of one XCD of the second reading every a-residue once each).
+// invert: the complement (256 - n CUs, exactly the ones the plain mask leaves out) — the two sides of a partition.
+static void balanced_cu_mask(int n_cus, bool invert, uint32_t mask[8]) {
+  const int k = n_cus / 32;
+  for (int w = 0; w < 8; ++w) mask[w] = 0;
+  for (int i = 0; i < 256; ++i) {
+    const bool in = ((i % 8) + (i / 8)) % 8 < k;
+    if (in != invert) mask[i >> 5] |= 1u << (i & 31);
+  }
+}
+
+// role "ENC" (a worker's encoder stream) or "DEC" (a decode lane's streams).  Environment, read per stream creation:
+//   FWAMD_<role>_STREAM_PRIO = high | low       stream priority (measured: no effect, profiles/r05_ab_stream_priority.jsonl)
+//   FWAMD_<role>_CUS = n | -n                   CU-masked stream: n CUs (multiple of 32, the same share of every XCD), or
+//                                               with a minus sign the 256 - n CUs the mask of n leaves out — so
+//                                               FWAMD_DEC_CUS=96 FWAMD_ENC_CUS=-96 is a disjoint 96 / 160 partition
+//                                               (profiles/r06_ab_overlap.jsonl).  CU-mask streams are BLOCKING streams: the
+//                                               hot path issues nothing on the default stream (results are copied on the decode stream), only set-up copies wait.
+hipError_t create_stream(hipStream_t* st, const char* role) {
+  char name[64];
+  snprintf(name, sizeof(name), "FWAMD_%s_CUS", role);
+  if (const char* c = getenv(name)) {
+    const int v = atoi(c), n = v < 0 ? -v : v;
+    if (n >= 32 && n <= 224 && n % 32 == 0) {
+      uint32_t mask[8];
+      balanced_cu_mask(n, v < 0, mask);
+      return hipExtStreamCreateWithCUMask(st, 8, mask);
+    }
+  }
+  snprintf(name, sizeof(name), "FWAMD_%s_STREAM_PRIO", role);
+  const char* e = getenv(name);
   if (e && (!strcmp(e, "high") || !strcmp(e, "low"))) {
     int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
@@ -1865,6 +1897,7 @@ int32_t fw_test_dec_linear(fw_model* fm, const float* x, const float* W, const f
 }
 
 int32_t fw_dec_big_min_rows(void) { return fwd::dec_big_min_rows(); }
+int32_t fw_dec_big_min_rows_of(int32_t role, int32_t compute_type) { return fwd::dec_big_min_rows_of(role, compute_type); }
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {

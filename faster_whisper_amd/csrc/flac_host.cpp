@@ -399,7 +399,10 @@ int32_t fw_flac_decode(const uint8_t* data, int64_t n_bytes, int32_t* out, int64
     }
     int take = block;
     if (inf.total > 0 && done + take > inf.total) take = (int)(inf.total - done);
-    if (done + take > capacity_samples) FL_FAIL("FLAC: output buffer of %lld samples per channel is too small", (long long)capacity_samples);
+    if (done + take > capacity_samples) {   // its own status: the caller grows the buffer and retries (no message matching)
+      fw::set_error("FLAC: output buffer of %lld samples per channel is too small", (long long)capacity_samples);
+      return FW_ENOSPC;
+    }
     pcm.resize((size_t)take * C * bytes_ps);
     size_t w = 0;
     for (int i = 0; i < take; ++i)

@@ -46,6 +46,7 @@ extern "C" {
 #define FW_ENODEV (-2)   /* no HIP device / HIP runtime failure       */
 #define FW_ENOMEM (-3)   /* device or host allocation failed          */
 #define FW_ERUNTIME (-4) /* kernel launch / internal error            */
+#define FW_ENOSPC (-5)   /* a caller-provided output buffer is too small (fw_flac_decode): retry with a larger one */
 
 /* 2: fw_model_set_encoder_cus / fw_model_encoder_cus removed, fw_model_set_merge_wait, fw_model_set_decode_lanes and
  *    fw_model_run_capacity added, test / bench hooks moved to fwamd_test.h; the cross-attention cache of a decode group
@@ -325,7 +326,8 @@ int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows
  * fw_flac_decode decodes the whole stream (host code, csrc/flac_host.cpp) into interleaved int32 samples
  * out[sample][channel] (capacity_samples per channel), verifying every frame's CRC-8 / CRC-16, and reports in md5_status
  * whether the decoded PCM carries the MD5 signature the encoder stored: 1 = yes (bit-exact decode), 0 = no, -1 = nothing
- * to compare with (no signature, or a truncated stream: the whole frames present are returned). */
+ * to compare with (no signature, or a truncated stream: the whole frames present are returned).
+ * FW_ENOSPC: the stream holds more than capacity_samples per channel (nothing usable was written): retry with a larger buffer. */
 int32_t fw_flac_info(const uint8_t* data, int64_t n_bytes, int32_t* sample_rate, int32_t* channels,
                      int32_t* bits_per_sample, int64_t* total_samples);
 int32_t fw_flac_decode(const uint8_t* data, int64_t n_bytes, int32_t* out, int64_t capacity_samples,

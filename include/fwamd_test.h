@@ -57,6 +57,10 @@ int32_t fw_bench_attention(fw_model* m, int32_t B, int32_t H, int32_t T, int32_t
 /* rows from which a decode run's per-layer linears take the GEMM-shaped kernel (dec_kernels.hip: DEC_BIG_MIN_ROWS);
  * bench.py prices the decoder linears against the MFMA roof from this row count on, against HBM below */
 int32_t fw_dec_big_min_rows(void);
+/* the same per linear: role 0 qkv, 1 d x d (out / cross-q / cross-out), 2 ffn1, 3 ffn2 (< 0: the lowest of the four);
+ * compute_type 0 float16, 1 int8_float16 (one row count for every linear).  Each linear switches at its own measured
+ * crossover, so a run between the lowest and the highest has some linears on either kernel: bench.py prices per role */
+int32_t fw_dec_big_min_rows_of(int32_t role, int32_t compute_type);
 /* process-wide measurement knob for A/B runs inside one process.  id 1: encoder GEMM tile order (1 = blocked, the
  * product's; 0 = n fastest across the whole width, rounds 1-3).  id 2: decoder self-attention form (0 = by launch size,
  * the product's; 1 = the first form of rounds 1-4; 2 = latency form; 3 = throughput form — all four return the same bits).  id 4 (3 was the weight prefetch of

@@ -320,3 +320,29 @@ def test_streamed_digital_silence_and_truncation_warning():
         y, _ = _read_flac(cut)
     assert 0 < y.shape[0] < bs * nb and y.shape[0] % bs == 0
     assert any("samples STREAMINFO announces" in str(w.message) for w in rec)
+
+
+def test_decompression_bomb_is_refused(monkeypatch):
+    """ADVICE (round 5): a small stream of CONSTANT frames may decode to hours of audio.  Above FWAMD_MAX_AUDIO_SECONDS the
+    reader raises a clear ValueError — for an announced length before any allocation, for a streamed encode (total = 0) once
+    the capped buffer has proved too small — instead of growing towards the format's ceiling; the C side reports the small
+    buffer with its own status (FW_ENOSPC), not by message text."""
+    from faster_whisper_amd import _lib
+    from faster_whisper_amd.audio import _read_flac
+    bs, nb = 4608, 40
+    pcm = np.zeros((bs * nb, 1), np.int64)
+    blocks = [(bs, [dict(kind="const")], None, 5)] * nb
+    lib = _lib.load()
+    for known in (True, False):
+        data = _stream(pcm, 16, 16000, blocks, known_length=known)
+        monkeypatch.setenv("FWAMD_MAX_AUDIO_SECONDS", "5")          # the stream holds 11.5 s
+        with pytest.raises(ValueError, match="FWAMD_MAX_AUDIO_SECONDS"):
+            _read_flac(data)
+        monkeypatch.setenv("FWAMD_MAX_AUDIO_SECONDS", "12")
+        x, _ = _read_flac(data)
+        assert x.shape == (bs * nb, 1)
+    import ctypes as C
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    out = np.zeros((10, 1), np.int32)
+    n, md5 = C.c_int64(), C.c_int32()
+    assert lib.fw_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), 10, C.byref(n), C.byref(md5)) == _lib.FW_ENOSPC

@@ -81,14 +81,15 @@ EXCEPTIONS = {
 # activations.  Everything not listed is asserted at NORTH_STAR.  enc = encoder output, relative (max, rms).
 FP16_VS_FP32 = ("fp16 storage of activations / attention probabilities through 32 + 32 layers against fp32 arithmetic "
                 "(CPU alone, fp16-emulating vs fp32 oracle: up to 3.0e-3 on a probability, tests/numerics_ln_fold_noise.py)")
+# Round 6 (verdict item 7): every row carries the largest value MEASURED on the box (profiles/r05_pytest_gpu.log:24-25,75-76,
+# chunks 0 / 13) and a bound of at most twice that — a regression of the size of the measurement itself fails the test.
+# Rows that round 5 listed and that measure inside the north star are gone (asserted at NORTH_STAR like everything else):
+# large-v3 beam-5 score (4.06e-4 / 5.8e-5), distil-large-v3 per token (1.34e-4 / 8.5e-5) and align (1.9e-4 / 1.1e-4).
 EXCEPTIONS_FP32 = {
-    ("large-v3 float16", "tf"): (4e-3, None, FP16_VS_FP32),
-    ("large-v3 float16", "beam"): (2e-3, None, FP16_VS_FP32),
-    ("large-v3 float16", "lang"): (1e-2, None, FP16_VS_FP32),
-    ("large-v3 float16", "align"): (6e-3, None, FP16_VS_FP32),
-    ("distil-large-v3 float16", "tf"): (2e-3, None, FP16_VS_FP32),
-    ("distil-large-v3 float16", "lang"): (4e-3, None, FP16_VS_FP32),
-    ("distil-large-v3 float16", "align"): (3e-3, None, FP16_VS_FP32),
+    ("large-v3 float16", "tf"): (1.2e-3, 5.56e-4, FP16_VS_FP32),
+    ("large-v3 float16", "lang"): (4e-3, 1.95e-3, FP16_VS_FP32),
+    ("large-v3 float16", "align"): (3e-3, 1.45e-3, FP16_VS_FP32),
+    ("distil-large-v3 float16", "lang"): (2e-3, 1.03e-3, FP16_VS_FP32),
 }
 
 
@@ -294,9 +295,10 @@ def _run(cfg, w, compute_type, tf_steps=8, beam_steps=48, long_steps=0, logits_r
               f"score of the same ids {sf:.5f} (rel {dlt:.2e})")
         expect(dlt < tol["beam"], f"{long_steps}-step run chunk {b}: {gl5[b].scores[0]} vs {sf}")
     # ---- the same engine results against the fp32 oracle, END TO END (the reference's CPU path is fp32 arithmetic) ----
-    if not i8:
-        _fp32_leg(cfg, w, compute_type, tag, expect, chunks, got, prompt, sup, tf_steps, beam_steps, g1, g5, gl, ga,
-                  text, nf, names)
+    # (int8_float16: the same leg as PRINTED figures only — the distance of per-row dynamic int8 from fp32 arithmetic is the
+    #  quantisation itself, tests/golden/numerics_int8_order_noise.txt; the asserted int8 bounds are EXCEPTIONS' rows above)
+    _fp32_leg(cfg, w, compute_type, tag, expect if not i8 else (lambda ok, msg: None), chunks, got, prompt, sup, tf_steps,
+              beam_steps, g1, g5, gl, ga, text, nf, names)
     # what the C2 test that follows reuses (same model, same 16-chunk results: one utterance must reproduce chunk 0)
     _LAST.clear()
     _LAST.update(key=(cfg.name, compute_type, id(w)), model=model, chunks=chunks, enc0=got[0].copy(), g5_0=g5[0],
