@@ -66,8 +66,34 @@ def host_model(backend, cfg):
     return wm
 
 
+def synthetic_vad(device_index=0):
+    """A Silero-VAD-v6-shaped network (the initializer names / shapes of the reference's ONNX asset, faster_whisper/vad.py:
+    288-351) with random weights, on the DEVICE path (csrc/vad.hip).  A random network answers ~ a constant; its output
+    layer (a 1 x 1 convolution before the sigmoid) is rescaled so that digital silence and the bench's noise land on
+    opposite sides of the threshold: logit' = gain * (logit - mid), mid / gain read off a calibration clip."""
+    from faster_whisper_amd import vad as fvad
+    rng = np.random.default_rng(3)
+    f = lambda *sh, scale=0.08: (rng.standard_normal(sh) * scale).astype(np.float32)   # noqa: E731
+    w = {"encoder.feature_extractor.forward_basis_buffer": f(258, 1, 256, scale=0.05),
+         "decoder.conv1d.weight": f(1, 128, 1, scale=0.3), "decoder.conv1d.bias": f(1, scale=0.1),
+         "onnx::LSTM_w": f(1, 512, 128), "onnx::LSTM_r": f(1, 512, 128), "onnx::LSTM_b": f(1, 1024, scale=0.2)}
+    for i, (co, ci) in enumerate([(128, 129), (64, 128), (64, 64), (128, 64)]):
+        w[f"encoder.conv_layers.{i}.weight"] = f(co, ci, 3)
+        w[f"encoder.conv_layers.{i}.bias"] = f(co, scale=0.05)
+    clip = np.concatenate([np.zeros(512 * 96, np.float32), synth_chunks(1, seed=5)[0][:512 * 96]])
+    p = np.asarray(fvad.SileroVADModel(weights=w, device="cuda", device_index=device_index)(clip), dtype=np.float64)
+    z = np.log(p / (1.0 - p))
+    z_sil, z_noise = float(np.median(z[8:88])), float(np.percentile(z[104:184], 2))
+    mid, gain = 0.5 * (z_sil + z_noise), 8.0 / max(1e-4, abs(z_noise - z_sil))
+    if z_noise < z_sil:
+        gain = -gain
+    w["decoder.conv1d.weight"] = (w["decoder.conv1d.weight"] * gain).astype(np.float32)
+    w["decoder.conv1d.bias"] = (w["decoder.conv1d.bias"] * gain - gain * mid).astype(np.float32)
+    return fvad.SileroVADModel(weights=w, device="cuda", device_index=device_index)
+
+
 def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0, shard=False, sync=None,
-                 word_timestamps=False):
+                 word_timestamps=False, vad=False):
     """End-to-end number (SURVEY.md section 8d wall-time definition): BatchedInferencePipeline.transcribe on one
     synthetic recording of n_chunks x 30 s that starts as an ndarray in HOST memory, timed until the last Segment is
     yielded — includes the host->device copy of the PCM, prompt / suppress-set construction, timestamp splitting and
@@ -83,15 +109,26 @@ def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0, shard=
         clips = [{"start": 30.0 * i, "end": 30.0 * (i + 1)} for i in range(n_chunks)]
         kw = dict(language="en", beam_size=beam, batch_size=batch, clip_timestamps=clips, max_new_tokens=new_tokens,
                   suppress_tokens=[cfg.eot], without_timestamps=True, word_timestamps=word_timestamps)
+        if vad:
+            # config C5: no clips — every 30 s slot ends in 2.5 s of digital silence, the native VAD (device kernels,
+            # csrc/vad.hip) finds the 27.5 s bursts inside the timed wall, collect_chunks makes one chunk of each
+            # (two padded spans exceed 30 s) and restore_speech_timestamps maps the times back
+            from faster_whisper_amd import vad as fvad
+            fvad._VAD_MODEL = synthetic_vad(getattr(backend, "device_index", [0])[0])
+            audio = audio.copy()
+            for i in range(n_chunks):
+                audio[480000 * i + 440000:480000 * (i + 1)] = 0.0
+            kw.pop("clip_timestamps")
+            kw["vad_filter"] = True
         if shard:
             kw["shard"] = True
         pipe = BatchedInferencePipeline(wm)
         n_warm = min(n_chunks, batch * max(1, int(getattr(backend, "inter_threads", 1))))
-        list(pipe.transcribe(audio[:480000 * n_warm], **dict(kw, clip_timestamps=clips[:n_warm]))[0])
+        list(pipe.transcribe(audio[:480000 * n_warm], **(kw if vad else dict(kw, clip_timestamps=clips[:n_warm])))[0])
         if sync:
             sync()
         t0 = time.perf_counter()
-        segments, _ = pipe.transcribe(audio, **kw)
+        segments, _info = pipe.transcribe(audio, **kw)
         n_seg = n_tok = n_words = 0
         digest = 0
         for s in segments:
@@ -110,6 +147,10 @@ def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0, shard=
                "what": "BatchedInferencePipeline.transcribe, ndarray in host memory -> last Segment"}
         if word_timestamps:
             out["words"] = n_words
+        if vad:
+            out["vad"] = "native device VAD inside the wall (fw_vad_forward_dev), vad_filter=True"
+            out["what"] = "BatchedInferencePipeline.transcribe(vad_filter=True), ndarray in host memory -> last Segment"
+            out["duration_after_vad_s"] = round(float(_info.duration_after_vad), 1)
         return out
     except Exception as e:   # a secondary number must never take the bench line down
         return {"error": f"{type(e).__name__}: {e}"}
@@ -122,10 +163,12 @@ def _multi(world):
     return world > 1 or os.environ.get("FWAMD_DIST_AT_WORLD_1") == "1"
 
 
+TIMES = {}     # start-up seconds of this rank that build_backend measures itself (blob_broadcast_s)
+
+
 def build_backend(args, cfg, rank, world, local_rank):
     """-> (backend, weights or None).  N > 1: rank 0 packs, RCCL broadcast, every rank builds from its HBM copy."""
     from faster_whisper_amd import Whisper, pack_blob, synthetic_weights
-    from faster_whisper_amd.sharding import broadcast_blob
     ct = 1 if args.compute_type == "int8_float16" else 0
     common = dict(device="cuda", device_index=local_rank, max_batch_size=args.batch, max_beam_size=args.beam,
                   inter_threads=args.workers, compute_type=args.compute_type)
@@ -135,17 +178,29 @@ def build_backend(args, cfg, rank, world, local_rank):
         common["merge_wait_ms"] = args.merge_wait_ms
     weights = None
     if _multi(world):
-        blob = None
+        # rank 0 builds its model from the weights (the packed blob is then in ITS HBM); the other ranks receive that
+        # allocation over RCCL / xGMI straight from rank 0's device memory — no 3 GB host image, no second upload
+        from faster_whisper_amd.sharding import broadcast_blob_dev
+        model = None
         if rank == 0:
             weights = synthetic_weights(cfg, seed=1234)
-            blob = pack_blob(cfg, weights, ct)
-        dev_blob = broadcast_blob(blob, rank, local_rank)           # RCCL broadcast over xGMI
-        model = Whisper(f"synthetic:{args.model}", blob_dev=(dev_blob.data_ptr(), dev_blob.numel()), **common)
-        model._blob_keepalive = dev_blob
+            model = Whisper(f"synthetic:{args.model}", files={"config": cfg, "weights": weights}, **common)
+        t_b = time.time()
+        dev_blob, nbytes = broadcast_blob_dev(model.blob() if rank == 0 else None, rank, local_rank)
+        import torch
+        torch.cuda.synchronize(local_rank)
+        TIMES["blob_broadcast_s"] = round(time.time() - t_b, 3)
+        TIMES["blob_bytes"] = nbytes
+        if rank != 0:
+            model = Whisper(f"synthetic:{args.model}", blob_dev=(dev_blob.data_ptr(), nbytes), **common)
+            model._blob_keepalive = dev_blob
     elif os.environ.get("FWAMD_BLOB_CACHE"):
         # profiling convenience: repeated invocations (rocprofv3 passes) reuse one packed weight blob
         import torch
-        cache = os.environ["FWAMD_BLOB_CACHE"] + f".{args.model}.{args.compute_type}.npy"
+        # (the plain LayerNorm / weight forms travel in the blob only when it is PACKED with FWAMD_LN_UNFOLD / FWAMD_PACK_PLAIN
+        #  set, engine.hip: pack_blob — a cache file made without them must not be handed to a process that asks for them)
+        plain = ".plain" if (os.environ.get("FWAMD_LN_UNFOLD", "0") not in ("", "0") or os.environ.get("FWAMD_PACK_PLAIN")) else ""
+        cache = os.environ["FWAMD_BLOB_CACHE"] + f".{args.model}.{args.compute_type}{plain}.npy"
         if os.path.exists(cache):
             blob = np.load(cache, mmap_mode="r")
         else:
@@ -228,6 +283,10 @@ def parse_args(argv=None):
                     help="float16 is the metric's configuration; int8_float16 times SURVEY section 8 config C3")
     ap.add_argument("--word-timestamps", action="store_true",
                     help="the pipeline measurement runs with word_timestamps=True (config C5: align pass timed)")
+    ap.add_argument("--vad", action="store_true",
+                    help="the pipeline measurement runs with vad_filter=True on the native device VAD (config C5: the recording "
+                         "has digital silences, the Silero network — synthetic weights, calibrated to separate them — runs "
+                         "INSIDE the timed wall, its spans are collected into chunks and the times restored)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -299,6 +358,11 @@ def main(argv=None, backend_factory=None, dist_backend=None):
     model, weights = (backend_factory or build_backend)(args, cfg, rank, world, local_rank)
     load_s = time.time() - t0
     phase("blob_broadcast_and_model")
+    if "blob_broadcast_s" in TIMES:          # (N > 1: the collective alone, measured inside build_backend)
+        phases["blob_broadcast"] = TIMES["blob_broadcast_s"]
+        if multi:
+            print(f"[bench rank {rank}/{world}] blob_broadcast (inside the phase above, {TIMES['blob_bytes'] / 1e9:.2f} GB "
+                  f"device -> device): {TIMES['blob_broadcast_s']:.2f} s", file=sys.stderr, flush=True)
 
     lanes = getattr(args, "decode_lanes", 2)
     if lanes != 2 and hasattr(model, "set_decode_lanes"):
@@ -431,7 +495,10 @@ def main(argv=None, backend_factory=None, dist_backend=None):
                    "steady_state_note": ("the timed region is at least two rounds of the worker pool" if args.steps >= 2 * W else
                                          f"{args.steps} steps < 2 x {W} workers: the timed region is ONE burst of the pool; "
                                          "`steady` holds the same measurement over 4 rounds"),
-                   "model_load_s": round(load_s, 1)},
+                   "model_load_s": round(load_s, 1),
+                   **({"blob_broadcast_s": TIMES["blob_broadcast_s"],
+                       "blob_broadcast_what": "RCCL broadcast of the packed weight blob from rank 0's device memory (no host "
+                                              "image); part of model_load_s"} if "blob_broadcast_s" in TIMES else {})},
     }
 
     # the combined roofline ceiling of this configuration (encoder MFMA + decode HBM, L = 100) is
@@ -576,7 +643,7 @@ def main(argv=None, backend_factory=None, dist_backend=None):
             out["families_rate"] = fam
         if secondary and not multi:
             out["pipeline"] = pipeline_rtf(model, cfg, args.pipeline_chunks, args.batch, args.beam, L,
-                                           word_timestamps=args.word_timestamps)
+                                           word_timestamps=args.word_timestamps, vad=args.vad)
             out["single_utterance"] = single_utterance(model, cfg, chunks[0], prompt, gen_kw(L), L)
             out["one_batch_at_a_time"] = one_batch(model, staged, chunks, prompt, gen_kw(L), L, args.batch)
         # ---- CPU baseline: the oracle (torch fp32 port) on a bounded sample of the same workload ----
@@ -634,9 +701,36 @@ def one_batch(model, staged, chunks, prompt, kw, L, batch, reps=4):
             model.generate(model.encode_pcm(c15), [prompt] * len(c15), **kw)        # PCM from host memory
             d = time.perf_counter() - t0
             best = d if best is None else min(best, d)
+        one_call = best
+        # the same 15 chunks as TWO sub-batches (8 + 7) on two host threads = what the batched driver does with a single
+        # batch and >= 2 workers (transcribe.py: _batched_segments_generator): the second half's encoder pass runs under
+        # the first half's decode run, the two runs decode side by side on the two lanes
+        halves = None
+        if getattr(model, "inter_threads", 1) >= 2 and len(c15) >= 4:
+            import threading
+            h = (len(c15) + 1) // 2
+            parts = [c15[:h], c15[h:]]
+
+            def half(i, out):
+                out[i] = model.generate(model.encode_pcm(parts[i]), [prompt] * len(parts[i]), **kw)
+
+            for rep in range(4):            # (first: warm — graphs of the two shapes)
+                out = [None, None]
+                ths = [threading.Thread(target=half, args=(i, out)) for i in range(2)]
+                t0 = time.perf_counter()
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                d = time.perf_counter() - t0
+                if rep:
+                    halves = d if halves is None else min(halves, d)
+            best = min(best, halves)
         return {"value": round(30.0 * batch / dt, 2), "unit": "audio-seconds per wall-second",
                 "latency_ms_per_batch": round(1e3 * dt, 1),
                 "c4_rank_batch": {"chunks": len(c15), "latency_ms": round(1e3 * best, 1),
+                                  "one_call_ms": round(1e3 * one_call, 1),
+                                  "two_halves_ms": None if halves is None else round(1e3 * halves, 1),
                                   "predicted_rtf_at_8_gpus_1h": round(3600.0 / best, 1),
                                   "what": "1 h = 120 chunks over 8 ranks = one 15-chunk batch per rank: wall = this latency "
                                           "(+ one gather); nothing merges at that size"},

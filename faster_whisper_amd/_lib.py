@@ -78,7 +78,7 @@ SYMBOLS = [
     "fw_prof_enable", "fw_prof_reset", "fw_prof_count", "fw_prof_name", "fw_prof_get", "fw_synchronize",
     "fw_dev_alloc", "fw_dev_free", "fw_dev_upload",
     "fw_test_gemm", "fw_test_layernorm", "fw_test_attention", "fw_test_dec_linear", "fw_test_dec_logits", "fw_test_logits_rules", "fw_bench_gemm", "fw_bench_dec_linear", "fw_bench_attention",
-    "fw_vad_create", "fw_vad_forward", "fw_vad_free", "fw_vad_forward_dev",
+    "fw_vad_create", "fw_vad_forward", "fw_vad_free", "fw_vad_forward_dev", "fw_vad_forward_audio_dev",
     "fw_flac_info", "fw_flac_decode",
 ]
 
@@ -172,6 +172,7 @@ def load():
     lib.fw_vad_forward.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.fw_vad_free.argtypes = [vp]
     lib.fw_vad_forward_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
+    lib.fw_vad_forward_audio_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
     lib.fw_vad_free.restype = None
     _lib = lib
     return lib

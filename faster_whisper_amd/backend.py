@@ -309,6 +309,13 @@ class Whisper:
     def config(self) -> WhisperConfig:
         return self._cfg
 
+    def blob(self, replica: int = 0) -> Tuple[int, int]:
+        """(device pointer, bytes) of the packed weight blob of a device's primary replica (fwamd.h: fw_model_blob) — what
+        rank 0 hands to sharding.broadcast_blob_dev and what `blob_dev=` takes on the other ranks"""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self._lib.fw_model_blob(self._replicas[self._primary_of(replica)].handle, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
     def set_decode_lanes(self, lanes: int):
         """decode runs a device's group may have in flight (fwamd.h: fw_model_set_decode_lanes): 2, or 1 for per-kernel timing"""
         for i in sorted({self._primary_of(r) for r in range(len(self._replicas))}):

@@ -37,6 +37,7 @@ void launch_self_attn(hipStream_t st, const half_t* qkv, int d, half_t* kc, half
                       int pos_fixed, int P, int R_total, int frag, int blk_n = 0);
 // 0: the product's choice by launch size; 1: the first form (rounds 1-4); 2: latency form; 3: throughput form (same bits)
 void set_self_attn_form(int form);
+void set_cross_attn_regs(int cap);   // fw_test_knob(7, ..): register cap of dec_cross_attn_kernel (0 none, 1: 96, 2: 80)
 // changes whenever a measurement knob changed the kernels a decode step launches: cached step graphs carry it
 int kernel_forms_epoch();
 void bump_kernel_forms_epoch();

@@ -19,6 +19,7 @@
 namespace fwd {
 static std::atomic<int> g_self_attn_form{0};   // fw_test_knob(2, ..): A/B of the self-attention forms
 static std::atomic<int> g_forms_epoch{0};      // bumped by every knob that changes which kernels a decode step launches
+static std::atomic<int> g_cross_regs{0};       // fw_test_knob(7, ..): 0 = uncapped (110 registers), 1 = capped at 96, 2 = at 80
 }
 
 // ------------------------------------------------------------------------------------
@@ -1166,8 +1167,12 @@ __global__ __launch_bounds__(MAXT) void dec_self_attn2_kernel(const half_t* __re
 // (row-shaped fragment loads of 64 B out of 16 different lines were texture-address bound).
 // The waves stride over 32-key groups with an online softmax each; merged through LDS.
 // ------------------------------------------------------------------------------------
-template <int CA_WAVES, bool NTL>
-__global__ __launch_bounds__(CA_WAVES * 64) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
+// MINW: minimum waves per SIMD the register allocation must allow (__launch_bounds__' second argument).  1 = whatever
+// the kernel wants (110 registers: 4 waves per SIMD = two workgroups per CU and nothing beside them); 5 caps it at 96
+// (4 values spilled) so that two workgroups leave a fifth wave slot of up to 128 registers per SIMD to a 4-wave workgroup of
+// the OTHER decode lane's linears / self-attention (knob 7, profiles/r06_ab_cross_regs.jsonl).
+template <int CA_WAVES, bool NTL, int MINW = 1>
+__global__ __launch_bounds__(CA_WAVES * 64, MINW) void dec_cross_attn_kernel(const half_t* __restrict__ qx, int d,
                                                              const half_t* __restrict__ ck,
                                                              const half_t* __restrict__ cvt, int T, int kvp,
                                                              int kmul, half_t* __restrict__ out,
@@ -2075,8 +2080,15 @@ void launch_cross_attn(hipStream_t st, const half_t* qx, int d, const half_t* ck
   // 8 waves per (chunk, head) keep 64 KB of loads in flight per workgroup (4 waves measured slower)
   // the K / V^T stream is read once per step and never again before 15 GB of other chunks have passed: non-temporal
   // loads (measured 75.3 -> 68.3 ms per batch, 5.4 -> 5.9 TB/s)
-  dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag, slot_map);
+  const int cap = g_cross_regs.load(std::memory_order_relaxed);
+  if (cap == 1)
+    dec_cross_attn_kernel<8, true, 5><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag, slot_map);
+  else if (cap == 2)
+    dec_cross_attn_kernel<8, true, 6><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag, slot_map);
+  else
+    dec_cross_attn_kernel<8, true><<<dim3(H, B), 512, 0, st>>>(qx, d, ck, cvt, T, kvp, kmul, out, done, kv_div, frag, slot_map);
 }
+void set_cross_attn_regs(int cap) { g_cross_regs.store(cap); g_forms_epoch.fetch_add(1); }
 
 void launch_nospeech(hipStream_t st, const float* logits, int V, int row_mul, int no_speech_id, float* out, int B) {
   dec_nospeech_kernel<<<B, 1024, 0, st>>>(logits, V, row_mul, no_speech_id, out);

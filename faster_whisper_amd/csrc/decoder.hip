@@ -652,6 +652,8 @@ static bool idle_balance() {
 // chunks an IDLE two-lane group wants queued before it leads a run: its even share of the work it knows of — `queued`
 // chunks in `n_queued` requests plus one request of that average size per worker inside an encode call — over the runs
 // that work needs (at least two: one per lane; more when it exceeds two runs' capacity `want`), never less than one batch
+// (round 6: splitting the known work of an idle group into at least THREE runs instead of two — the first run starting after a
+//  third of a burst's encoder passes — measured +-0.4 % on the 20-batch burst and on the steady state: profiles/r06_ab_idle_runs.jsonl)
 int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch) {
   const int64_t per_req = std::max<int64_t>(1, queued / std::max<int64_t>(1, (int64_t)n_queued));
   const int64_t outstanding = queued + (int64_t)std::max(0, encoding) * per_req;

@@ -1901,8 +1901,9 @@ int32_t fw_dec_big_min_rows_of(int32_t role, int32_t compute_type) { return fwd:
 
 // process-wide measurement knobs (A/B inside one process: profiles/gemm_bench.py); 1: encoder GEMM tile order
 int32_t fw_test_knob(int32_t id, int32_t value) {
-  FW_CHECK_ARG(id == 1 || id == 2 || id == 4 || id == 5 || id == 6, "unknown knob %d", id);
+  FW_CHECK_ARG(id == 1 || id == 2 || id == 4 || id == 5 || id == 6 || id == 7, "unknown knob %d", id);
   if (id == 6) { set_cross_kv_layered(value); return FW_OK; }
+  if (id == 7) { fwd::set_cross_attn_regs(value); return FW_OK; }
   if (id == 1) fwk::g_gemm_order.store(value);
   else if (id == 5) fwk::g_gemm_vt_stage.store(value);
   else if (id == 2) fwd::set_self_attn_form(value);

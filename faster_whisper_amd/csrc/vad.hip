@@ -1,8 +1,7 @@
 // Silero VAD v6 on the GPU (MI355X-first form of csrc/vad_host.cpp).
 //
-// STATUS: written after the GPU budget of round 1 was spent — compiles for gfx950, NOT yet run on hardware.
-// Nothing calls it by default (SileroVADModel(device="cuda") opts in; the GPU test is gated by
-// FWAMD_TEST_UNVALIDATED=1).  The host C++ path stays the default until this one is validated.
+// Validated on hardware against oracle/silero.py and the host path since round 4 (tests/test_gpu_vad.py, tests/test_gpu_c5.py);
+// SileroVADModel(device="cuda") selects it.
 //
 // Two kernels (one hour of audio = 112 500 windows):
 //   vad_front_kernel   one workgroup per 512-sample window: reflect pad, STFT as a [258 x 256] matrix product
@@ -36,7 +35,8 @@ __global__ __launch_bounds__(256) void vad_front_kernel(const float* __restrict_
                                                         const float* __restrict__ cw2, const float* __restrict__ cb2,
                                                         const float* __restrict__ cw3, const float* __restrict__ cb3,
                                                         const float* __restrict__ lw_t, const float* __restrict__ lb,
-                                                        float* __restrict__ gx) {
+                                                        float* __restrict__ gx, const float* __restrict__ audio,
+                                                        int64_t n_windows) {
   __shared__ float xp[kPadded];
   __shared__ float spec[kFrames][2 * kBins];
   __shared__ float mag[kFrames][kBins + 3];
@@ -45,11 +45,23 @@ __global__ __launch_bounds__(256) void vad_front_kernel(const float* __restrict_
   __shared__ float a2[64];
   __shared__ float feat[128];
   const int tid = threadIdx.x;
-  const float* w = win + (size_t)blockIdx.x * kWin;
-  for (int i = tid; i < kWin; i += 256) xp[kPad + i] = w[i];
+  // sample j of this window.  win: the caller framed [context 64 | window 512] rows.  audio (round 6): framed HERE, as the
+  // reference's SileroVADModel.__call__ does on the host (vad.py:318-336): the context of window i is the tail of window
+  // i - 1 (zeros for the first window) and the last 64 samples of the LAST window are zeroed (its in-place
+  // `context[-1] = 0` on a view) — no [n][576] copy of the recording is built on the host or sent over PCIe
+  const int64_t wi = blockIdx.x;
+  const float* w = win ? win + (size_t)wi * kWin : nullptr;
+  auto sample = [&](int j) -> float {
+    if (w) return w[j];
+    if (j < 64) return wi == 0 ? 0.f : audio[(wi - 1) * 512 + 448 + j];
+    const int jj = j - 64;
+    if (wi == n_windows - 1 && jj >= 448) return 0.f;
+    return audio[wi * 512 + jj];
+  };
+  for (int i = tid; i < kWin; i += 256) xp[kPad + i] = sample(i);
   if (tid < kPad) {
-    xp[tid] = w[kPad - tid];                     // reflect, edge sample not repeated
-    xp[kPad + kWin + tid] = w[kWin - 2 - tid];
+    xp[tid] = sample(kPad - tid);                // reflect, edge sample not repeated
+    xp[kPad + kWin + tid] = sample(kWin - 2 - tid);
   }
   __syncthreads();
   // STFT: frames 1..4 of the stride-128 convolution (frame 0 is sliced away by the graph)
@@ -210,9 +222,10 @@ void fw_vad_dev_release(void* dev) {
   delete d;
 }
 
-extern "C" int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows, int64_t n, float* h,
-                                      float* c, float* probs) {
-  FW_CHECK_ARG(v && h && c && (n == 0 || (windows && probs)), "null argument");
+// windows != null: n framed rows of 576 samples; audio != null: n * 512 samples, framed on the device
+static int32_t vad_forward_dev_impl(fw_vad* v, int32_t device_index, const float* windows, const float* audio, int64_t n,
+                                    float* h, float* c, float* probs) {
+  FW_CHECK_ARG(v && h && c && (n == 0 || ((windows || audio) && probs)), "null argument");
   FW_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31), "window count out of range");
   if (n == 0) return FW_OK;
   int ndev = 0;
@@ -238,16 +251,18 @@ extern "C" int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const flo
       return e_ == hipErrorOutOfMemory ? FW_ENOMEM : FW_ERUNTIME;                            \
     }                                                                                        \
   } while (0)
-  VAD_TRY(hipMalloc(reinterpret_cast<void**>(&dwin), (size_t)n * kWin * sizeof(float)));
+  const size_t in_floats = windows ? (size_t)n * kWin : (size_t)n * 512;
+  VAD_TRY(hipMalloc(reinterpret_cast<void**>(&dwin), in_floats * sizeof(float)));
   VAD_TRY(hipMalloc(reinterpret_cast<void**>(&dgx), (size_t)n * kGates * sizeof(float)));
   VAD_TRY(hipMalloc(reinterpret_cast<void**>(&dh), kHidden * sizeof(float)));
   VAD_TRY(hipMalloc(reinterpret_cast<void**>(&dc), kHidden * sizeof(float)));
   VAD_TRY(hipMalloc(reinterpret_cast<void**>(&dp), (size_t)n * sizeof(float)));
-  VAD_TRY(hipMemcpyAsync(dwin, windows, (size_t)n * kWin * sizeof(float), hipMemcpyHostToDevice, d->st));
+  VAD_TRY(hipMemcpyAsync(dwin, windows ? windows : audio, in_floats * sizeof(float), hipMemcpyHostToDevice, d->st));
   VAD_TRY(hipMemcpyAsync(dh, h, kHidden * sizeof(float), hipMemcpyHostToDevice, d->st));
   VAD_TRY(hipMemcpyAsync(dc, c, kHidden * sizeof(float), hipMemcpyHostToDevice, d->st));
-  vad_front_kernel<<<(unsigned)n, 256, 0, d->st>>>(dwin, d->basis_t, d->cw_t[0], d->cb[0], d->cw_t[1], d->cb[1], d->cw_t[2],
-                                                   d->cb[2], d->cw_t[3], d->cb[3], d->lw_t, d->lb, dgx);
+  vad_front_kernel<<<(unsigned)n, 256, 0, d->st>>>(windows ? dwin : nullptr, d->basis_t, d->cw_t[0], d->cb[0], d->cw_t[1],
+                                                   d->cb[1], d->cw_t[2], d->cb[2], d->cw_t[3], d->cb[3], d->lw_t, d->lb, dgx,
+                                                   windows ? nullptr : dwin, n);
   vad_lstm_kernel<<<1, 512, 0, d->st>>>(dgx, d->lr_t, d->dw, d->db, n, dh, dc, dp);
   VAD_TRY(hipGetLastError());
   VAD_TRY(hipMemcpyAsync(probs, dp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, d->st));
@@ -257,4 +272,15 @@ extern "C" int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const flo
 #undef VAD_TRY
   cleanup();
   return FW_OK;
+}
+
+extern "C" int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows, int64_t n, float* h,
+                                      float* c, float* probs) {
+  return vad_forward_dev_impl(v, device_index, windows, nullptr, n, h, c, probs);
+}
+
+extern "C" int32_t fw_vad_forward_audio_dev(fw_vad* v, int32_t device_index, const float* audio, int64_t n_samples,
+                                            float* h, float* c, float* probs) {
+  FW_CHECK_ARG(n_samples >= 0 && n_samples % 512 == 0, "the recording must be padded to a multiple of 512 samples");
+  return vad_forward_dev_impl(v, device_index, nullptr, audio, n_samples / 512, h, c, probs);
 }

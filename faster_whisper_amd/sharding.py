@@ -3,7 +3,9 @@
 
 The path shards by independent units (30 s chunks): no collective in
 the data path.  Only two exchanges exist:
-  * load time:  rank 0 packs the weight blob, `broadcast_blob` sends it to every rank's HBM;
+  * load time:  rank 0 builds its model (the packed weight blob is then in its HBM) and `broadcast_blob_dev` sends that
+                allocation to every other rank's HBM over RCCL — no host image, no second upload (`broadcast_blob`, the
+                host-image form, stays for the gloo seam of the CPU tests);
   * per batch:  `gather_results` brings the fixed-size result records (ids, length, score,
                 no_speech_prob) to rank 0, in rank order, so the output order equals the
                 serial reference's order.
@@ -48,6 +50,35 @@ def broadcast_blob(blob: Optional[np.ndarray], rank: int, local_rank: int):
         t = torch.empty(n, dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=0)
     return t
+
+
+class _DeviceBytes:
+    """`n` bytes of device memory at `ptr` as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def broadcast_blob_dev(blob_dev: Optional[Tuple[int, int]], rank: int, local_rank: int):
+    """Round 6: the broadcast WITHOUT a host bounce.  Rank 0 has already built its model (the packed blob lives in ITS HBM:
+    `Whisper.blob()` = fw_model_blob's pointer and size) and passes (ptr, nbytes); RCCL reads straight from that allocation
+    (wrapped as a tensor, no copy) and every other rank receives into a fresh device buffer.  Returns (tensor, nbytes): on
+    rank 0 the zero-copy view of the model's own blob, elsewhere the received buffer (keep it alive as long as the model
+    built on it).  nccl only — the CPU seam (gloo) keeps `broadcast_blob` on the host image."""
+    import torch
+    dist = _dist()
+    assert dist.get_backend() == "nccl", "broadcast_blob_dev needs device memory on every rank (backend nccl = RCCL)"
+    dev = torch.device("cuda", local_rank)
+    size = torch.tensor([blob_dev[1] if rank == 0 else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(size, src=0)
+    n = int(size.item())
+    if rank == 0:
+        t = torch.as_tensor(_DeviceBytes(blob_dev[0], n), device=dev)
+        assert t.data_ptr() == blob_dev[0], "the wrapped blob must alias the model's allocation (no copy)"
+    else:
+        t = torch.empty(n, dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)
+    return t, n
 
 
 RECORD_EXTRA = 5   # int32 words besides the ids: length + two float64

@@ -987,6 +987,13 @@ class BatchedInferencePipeline:
         def batches(lo, hi):
             """(outs, local, aligned) per batch of the chunk range [lo, hi), in order, `workers` batches in flight"""
             spans = [(i, min(hi, i + batch_size)) for i in range(lo, hi, batch_size)]
+            if workers >= 2 and len(spans) == 1 and hi - lo >= 4:
+                # ONE batch and idle workers (a rank's share of a sharded recording: 1 h over 8 GPUs = 15 chunks): two
+                # half batches on two workers — the second half's encoder pass runs under the first half's decode run and
+                # the two runs decode side by side on the group's two lanes.  Results do not depend on the split (every
+                # kernel works per chunk); measured 315 -> 290 ms for 15 chunks (profiles/r06_bench_c4_halves.json)
+                mid = lo + (hi - lo + 1) // 2
+                spans = [(lo, mid), (mid, hi)]
             if workers <= 1 or len(spans) <= 1:
                 for sp in spans:
                     yield decode_batch(*sp)

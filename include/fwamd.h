@@ -319,6 +319,13 @@ void fw_vad_free(fw_vad* v);
  * path by default (the reference runs the VAD on the CPU, vad.py:295-351). */
 int32_t fw_vad_forward_dev(fw_vad* v, int32_t device_index, const float* windows, int64_t n, float* h, float* c,
                            float* probs);
+/* The same network over a whole RECORDING: `audio` = n_samples float32 samples in host memory, n_samples a multiple of 512
+ * (the reference pads with 1..512 zeros, vad.py:79-81); the 576-sample rows [64 context | 512 window] the network takes are
+ * formed on the device exactly as SileroVADModel.__call__ forms them on the host (faster_whisper/vad.py:318-336: context
+ * = tail of the previous window, zeros for the first; the last 64 samples of the last window zeroed), so no [n][576] copy
+ * of the recording is built or transferred.  probs: n_samples / 512 values. */
+int32_t fw_vad_forward_audio_dev(fw_vad* v, int32_t device_index, const float* audio, int64_t n_samples, float* h, float* c,
+                                 float* probs);
 
 /* ---- audio front: native FLAC decoding --------------------------------------------
  * The reference decodes every container through PyAV / FFmpeg (faster_whisper/audio.py:19-76); its own test asset

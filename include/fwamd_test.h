@@ -68,7 +68,8 @@ int32_t fw_dec_big_min_rows_of(int32_t role, int32_t compute_type);
  * up to 16 positions per decoder pass; 0: one position per pass, rounds 1-4 — the same bits).  id 5: the plain transposed
  * GEMM epilogue, i.e. the encoder's V^T (1, the default: staged through LDS, whole row segments of Ct; 0: direct 8-byte stores,
  * rounds 1-4 — the same bits).  id 6: the cross-attention K / V^T projections (1, the default: all decoder layers in two
- * launches of the encoder GEMM; 0: two launches per layer, rounds 1-4 — the same bits) */
+ * launches of the encoder GEMM; 0: two launches per layer, rounds 1-4 — the same bits).  id 7: register cap of the decoder
+ * cross-attention kernel (0, the default: none, 110 registers; 1: 96; 2: 80 — the same bits; profiles/r06_ab_cross_regs.jsonl) */
 int32_t fw_test_knob(int32_t id, int32_t value);
 /* host-only (no device needed): chunks an IDLE two-lane decode group wants queued before it leads a run — its even share of
  * the work it knows of (`queued` chunks in `n_queued` requests + one request of that average size per worker inside an encode

@@ -65,3 +65,8 @@ def test_bench_one_rank_over_rccl(tmp_path):
     # what rank 0 assembled from the RCCL gather == what the unsharded pipeline yields
     assert sh["segments"] == serial["segments"] and sh["tokens"] == serial["tokens"]
     assert sh["digest"] == serial["digest"], (sh, serial)
+    # round 6: the weight blob travels device -> device (sharding.broadcast_blob_dev wraps fw_model_blob's allocation, no
+    # host image); the line says how long the collective alone took, apart from model_load_s
+    # (model_load_s is rounded to 0.1 s in the line; micro loads in milliseconds)
+    assert 0.0 <= j["config"]["blob_broadcast_s"] <= j["config"]["model_load_s"] + 0.1
+    assert "blob_broadcast (inside the phase above" in p.stderr

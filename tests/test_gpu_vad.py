@@ -66,3 +66,40 @@ def test_device_vad_matches_host():
     a, b = host(audio), dev(audio)
     assert a.shape == b.shape == (1000,)
     assert np.abs(a - b).max() < 5e-5
+
+
+def test_device_framing_equals_host_framing():
+    """round 6: fw_vad_forward_audio_dev frames the recording on the device (context = tail of the previous window, zeros
+    for the first, last 64 samples of the last window zeroed: faster_whisper/vad.py:318-336); the probabilities must be
+    the ones the host-framed rows give through fw_vad_forward_dev, bit for bit, and the LSTM state too"""
+    import ctypes as C
+    from faster_whisper_amd import _lib, vad
+    from oracle import silero
+    from test_vad_network import synthetic_weights
+    w = synthetic_weights(5)
+    dev = vad.SileroVADModel(weights=w, device="cuda")
+    lib = _lib.load()
+    for n_win in (1, 2, 37, 800):
+        audio = _audio(max(n_win, 10), seed=n_win)[:512 * n_win]
+        win = silero.frame_windows(audio)
+        assert win.shape == (n_win, 576)
+        out = []
+        for mode in (0, 1):
+            h = np.zeros(128, np.float32)
+            c = np.zeros(128, np.float32)
+            p = np.empty(n_win, np.float32)
+            if mode == 0:
+                _lib.check(lib.fw_vad_forward_dev(dev._handle, 0, _lib.ptr(np.ascontiguousarray(win)), n_win, _lib.ptr(h),
+                                                  _lib.ptr(c), _lib.ptr(p)))
+            else:
+                a = np.ascontiguousarray(audio)
+                _lib.check(lib.fw_vad_forward_audio_dev(dev._handle, 0, _lib.ptr(a), a.shape[0], _lib.ptr(h), _lib.ptr(c),
+                                                        _lib.ptr(p)))
+            out.append((p, h, c))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        assert np.array_equal(out[0][2], out[1][2])
+        assert np.array_equal(dev(audio), out[1][0])           # what SileroVADModel.__call__ now takes
+    with pytest.raises(ValueError):
+        a = np.zeros(700, np.float32)
+        h = np.zeros(128, np.float32)
+        _lib.check(lib.fw_vad_forward_audio_dev(dev._handle, 0, _lib.ptr(a), 700, _lib.ptr(h), _lib.ptr(h), _lib.ptr(a)))

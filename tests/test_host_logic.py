@@ -147,3 +147,48 @@ def test_idle_decode_group_splits_known_work_evenly():
     assert f(11 + 16, 2, 2, cap, 16) == (27 + 2 * 13 + 1) // 2
     # degenerate arguments do not divide by zero
     assert f(0, 0, 0, 0, 1) == 1 and f(16, 0, -3, cap, 16) == 16
+
+
+def test_speech_timestamps_skip_ahead_equals_every_window():
+    """round 6: get_speech_timestamps jumps over the windows that cannot change its state (an 8 h recording is 900 000
+    windows); the plain walk over every window — the reference's loop, vad.py:85-160 — must give the same spans for any
+    probabilities and options: run lengths around every duration threshold, probabilities inside the hysteresis band,
+    over-long speech with and without a cut candidate"""
+    from faster_whisper_amd.vad import VadOptions, get_speech_timestamps
+    rng = np.random.default_rng(2024)
+    n_cases = 0
+    for case in range(400):
+        n = int(rng.integers(1, 1500))
+        kind = case % 4
+        if kind == 0:                                   # i.i.d. noise around the thresholds
+            p = rng.uniform(0.2, 0.8, n)
+        elif kind == 1:                                 # long runs of speech / silence / in-band values
+            p = np.empty(n)
+            i = 0
+            while i < n:
+                run = int(rng.integers(1, 120))
+                p[i:i + run] = rng.choice([0.02, 0.3, 0.42, 0.6, 0.97]) + rng.uniform(-0.01, 0.01)
+                i += run
+        elif kind == 2:                                 # mostly speech with short dips: exercises the max-duration cuts
+            p = np.full(n, 0.9)
+            for _ in range(int(rng.integers(0, 12))):
+                a = int(rng.integers(0, n))
+                p[a:a + int(rng.integers(1, 9))] = rng.choice([0.1, 0.4])
+        else:                                           # mostly silence with bursts
+            p = np.full(n, 0.05)
+            for _ in range(int(rng.integers(0, 10))):
+                a = int(rng.integers(0, n))
+                p[a:a + int(rng.integers(1, 200))] = 0.8
+        opts = VadOptions(threshold=float(rng.choice([0.5, 0.35, 0.6])),
+                          neg_threshold=None if rng.random() < 0.6 else float(rng.choice([0.2, 0.3])),
+                          min_speech_duration_ms=int(rng.choice([0, 100, 250])),
+                          max_speech_duration_s=float(rng.choice([float("inf"), 30.0, 4.0, 1.5])),
+                          min_silence_duration_ms=int(rng.choice([160, 2000, 500, 64])),
+                          speech_pad_ms=int(rng.choice([400, 30, 0])))
+        audio = np.zeros(512 * n - int(rng.integers(0, 512)) if n > 1 else 300, np.float32)
+        probs = p[:len(audio) // 512 + 1] if len(audio) // 512 + 1 <= n else p
+        fast = get_speech_timestamps(audio, opts, speech_probs=probs)
+        slow = get_speech_timestamps(audio, opts, speech_probs=probs, _every_window=True)
+        assert fast == slow, (case, opts, fast[:3], slow[:3])
+        n_cases += bool(slow)
+    assert n_cases > 200          # most cases do produce spans
