@@ -312,6 +312,11 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 // k-step with four waves issuing (25 B/clk per CU: the LDS-DMA issue, not its latency — a deeper ring, or touching the
 // lines of later stages into L2 ahead of time, made it slower), the MFMA side alone ~550.
 // ------------------------------------------------------------------------------------
+// cycle stamps for profiles/ubench/dec_big_timeline.hip (defined there before this file is included); nothing otherwise
+#ifndef DGB_TL
+#define DGB_TL(slot) do {} while (0)
+#define DGB_TL_DECL
+#endif
 template <int N_>
 static __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
     half_t* __restrict__ out, int ldo, half_t* __restrict__ out_frag, int R, int N, int K, int act, int nNt) {
   constexpr int NW = WM * WN;
+  DGB_TL_DECL;
   constexpr int PX = 4 * WM, PW = FB * WN, PCS = PX + PW;   // fragments (1 KB pieces) of one k-step: x row tiles, W column tiles
   static_assert((PCS * KC) % NW == 0, "pieces of a stage must divide over the waves");
   static_assert(FB == 2 || FB == 4, "column tiles per wave");
@@ -397,29 +403,35 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     for (int b = 0; b < FB; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
   }
 
-  auto compute = [&](int slot) {          // the MFMAs of one stage
+  half8_t xv[KC][4], wv[KC][FB];          // the stage's fragments: fetch() -> LDS reads, mma() -> the MFMAs
+  auto fetch = [&](int slot) {
     const char* st = dgb_smem + slot * STAGE_BYTES;
-    // every fragment of the stage is requested up front, the MFMAs then follow the counted LDS waits
-    half8_t xv[KC][4], wv[KC][FB];
+    // every fragment of the stage is requested up front — the x fragments first, then the W fragments — and the MFMAs run W
+    // fragment by W fragment: the LayerNorm statistics need only the x fragments and the first four MFMAs only the first W
+    // fragment, so the compiler's counted LDS waits let the matrix pipe start while the later W fragments are still on their
+    // way (round 6: with W first and the loops the other way round the stream opened with `s_waitcnt lgkmcnt(0)` — the
+    // whole 8 KB read burst of the wave exposed in front of its first MFMA: profiles/r06_dec_big_timeline.txt).  The order
+    // of MFMAs on DIFFERENT accumulators does not enter any result.
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
-#pragma unroll
-      for (int b = 0; b < FB; ++b)
-        wv[ks][b] = *reinterpret_cast<const half8_t*>(st + (((PX + wn * FB + b) * KC + ks) * 64 + lane) * 16);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
         xv[ks][a] = *reinterpret_cast<const half8_t*>(st + (((wm * 4 + a) * KC + ks) * 64 + lane) * 16);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+        wv[ks][b] = *reinterpret_cast<const half8_t*>(st + (((PX + wn * FB + b) * KC + ks) * 64 + lane) * 16);
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&]() {                      // the MFMAs of the fetched stage
+    __builtin_amdgcn_sched_barrier(0);
+    DGB_TL(4);
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
+      if (LNF) {
+        const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < FB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][b], xv[ks][a], acc[a][b], 0, 0, 0);
-        if (LNF) {
-          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+        for (int a = 0; a < 4; ++a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const half2_t h2 = {xv[ks][a][2 * e], xv[ks][a][2 * e + 1]};
@@ -428,8 +440,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
           }
         }
       }
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][b], xv[ks][a], acc[a][b], 0, 0, 0);
+      }
     }
   };
+  auto compute = [&](int slot) { fetch(slot); mma(); };
   auto slice_end = [&]() {                // the skinny kernel's fixed-order reduction, one term at a time
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -473,11 +492,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     if (grp == 0) {
       int slot = 0, fill = LEAD;
       for (int c = 0; c < n_steady; ++c) {
+        DGB_TL(0);
         DGB_BARRIER();                        // A(c)
+        DGB_TL(1);
         issue(c + LEAD, fill);
+        DGB_TL(2);
         wait_vmcnt<LEAD * PPW>();             // own pieces of stage c (LEAD younger stages stay in flight)
         DGB_BARRIER();                        // B(c)
+        DGB_TL(3);
         compute(slot);
+        DGB_TL(5);
         if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
         slot = next(slot); fill = next(fill);
       }
@@ -502,12 +526,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
       issue(LEAD, fill);
       fill = next(fill);
       for (int c = 1; c < n_steady; ++c) {
+        DGB_TL(0);
         DGB_BARRIER();                        // A(c)
+        DGB_TL(1);
         compute(slot);                        // stage c - 1
         if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+        DGB_TL(2);
         wait_vmcnt<(LEAD - 1) * PPW>();       // own pieces of stage c
         DGB_BARRIER();                        // B(c)
+        DGB_TL(3);
         issue(c + LEAD, fill);
+        DGB_TL(5);
         slot = next(slot); fill = next(fill);
       }
       auto tail1 = [&](auto jc) {
@@ -535,10 +564,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const int n_steady = nch - (NST - 1);
     // steady state: stages c .. c + NST - 2 are in flight; wait until only the NST - 2 younger ones are
     for (int c = 0; c < n_steady; ++c) {
+      DGB_TL(0);
       wait_vmcnt<(NST - 2) * PPW>();
+      DGB_TL(1);
       DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
-      issue(c + NST - 1, fill);             // ... whose slot is the one refilled now
-      compute(slot);
+      DGB_TL(2);
+      // the LDS reads of stage c leave BEFORE the DMA of stage c + NST - 1 is issued (round 6): the ~270 cycles a wave spends
+      // issuing its global_load_lds pieces now run under the latency of its own 8 KB read burst instead of in front of it
+      // (profiles/r06_dec_big_timeline.txt: barrier | issue 267-478 | reads + lgkmcnt(0) wait | MFMAs, all in series)
+      fetch(slot);
+      DGB_TL(3);
+      issue(c + NST - 1, fill);             // ... whose slot (stage c - 1's) is the one refilled now
+      mma();
+      DGB_TL(5);
       if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
       fill = slot;
       slot = (slot + 1 == NST) ? 0 : slot + 1;
@@ -1899,10 +1937,13 @@ static int dec_linear_role(int N, int K) { return N == 3 * K ? 0 : (N >= 2560 ? 
 // profiles/r05_dec_linear_bench_call1.txt (round 5), profiles/r06_dec_linear_bench_*.txt (round 6: staggered 256 x 128).
 struct DecBigRule { int rows; int cfg; };
 static const DecBigRule DEC_BIG_RULES[4][2] = {
+    // (round 6, profiles/r06_dec_linear_bench_call9_reads_first.txt, us per launch register-streaming vs LDS-staged at 800 /
+    //  960 / 1 280 rows: d x d 10.0 / 11.8 / 15.8 vs 12.2 / 12.4 / 12.7, ffn1 35.2 / 41.5 / 52.9 vs 33.8 / 35.1 / 37.4 (128 x 128:
+    //  from 1 280 rows the 256 x 128 form is the same), ffn2 33.1 / 39.2 / 51.2 vs 33.4 / 33.7 / 36.8)
     /* qkv  */ {{704, 2}, {1280, 0}},
-    /* dxd  */ {{1120, 1}, {1 << 30, 1}},
-    /* ffn1 */ {{864, 0}, {1 << 30, 0}},
-    /* ffn2 */ {{896, 1}, {1 << 30, 1}},
+    /* dxd  */ {{1024, 1}, {1 << 30, 1}},
+    /* ffn1 */ {{800, 2}, {1280, 0}},
+    /* ffn2 */ {{832, 1}, {1 << 30, 1}},
 };
 static int dec_big_cfg_for(int R, int N, int K) {
   const DecBigRule* r = DEC_BIG_RULES[dec_linear_role(N, K)];

@@ -12,6 +12,7 @@
 //                      recurrence matrix R[512][128] in 128 VGPRs, h[128] lives in LDS (broadcast reads), two
 //                      barriers per step; c stays in the registers of the first 128 threads.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "engine.h"
@@ -153,8 +154,19 @@ __global__ __launch_bounds__(512) void vad_lstm_kernel(const float* __restrict__
   for (int64_t i = 0; i < n; ++i) {
     float g = g_next;
     if (i + 1 < n) g_next = gx[(size_t)(i + 1) * kGates + r];           // in flight during the dot product
+    // four interleaved partial sums (k = 0, 4, 8, ... / 1, 5, ... / ...): the step is a chain of DEPENDENT fused
+    // multiply-adds — 128 in a row were ~0.45 us of the ~1.1 us a step took, and an 8 h recording is 900 000 steps in front
+    // of the first transcribed chunk (profiles/r06_vad_bench.json); the order of the additions differs from the host path's
+    // k-ascending sum by fp32 round-off only (tests/test_gpu_vad.py: 1e-4 / 5e-5 bounds, measured ~1e-7)
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f;
 #pragma unroll
-    for (int k = 0; k < kHidden; ++k) g += R[k] * hs[k];                 // LDS broadcast reads, k ascending
+    for (int k = 0; k < kHidden; k += 4) {                               // LDS broadcast reads
+      g += R[k] * hs[k];
+      g1 += R[k + 1] * hs[k + 1];
+      g2 += R[k + 2] * hs[k + 2];
+      g3 += R[k + 3] * hs[k + 3];
+    }
+    g = (g + g1) + (g2 + g3);
     gs[r] = g;
     __syncthreads();
     if (r < kHidden) {   // ONNX gate order i, o, f, c
@@ -175,6 +187,10 @@ __global__ __launch_bounds__(512) void vad_lstm_kernel(const float* __restrict__
   }
 }
 
+// (Round 6 measured a second form — four waves, two gate rows per lane, the four gates of a unit meeting by one cross-lane
+//  exchange, h double-buffered so that a step has ONE barrier — at 2.30 s for the 900 000 windows of an 8 h recording against
+//  1.79 s for the form above: 256 registers of recurrence matrix per lane and half the waves to hide the LDS broadcast reads.
+//  Removed; profiles/r06_vad_bench_call9_lstm_forms.json.)
 template <typename T>
 int upload(const std::vector<T>& src, T** dst) {
   FW_HIP(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(T)));
