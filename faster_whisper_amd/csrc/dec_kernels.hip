@@ -330,6 +330,9 @@ static __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("" ::: "memory");         \
   } while (0)
 
+// workgroup barrier WITH the LDS fence (plain data exchange through LDS, outside the K loop)
+#define DGB_BARRIER_LDS() __syncthreads()
+
 template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST, bool STG = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
@@ -394,11 +397,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
                                        (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
   };
 
+  static_assert(!LNF || WN == 2, "the LayerNorm statistics are shared by the TWO waves of a row block");
   floatx4 acc[4][FB], tot[4][FB];
-  float rs[4], rq[4], sa[4], sb[4];
+  float rs[2] = {0.f, 0.f}, rq[2] = {0.f, 0.f}, sal[2] = {0.f, 0.f}, sbl[2] = {0.f, 0.f};   // this wave's two row tiles
+  float sa[4], sb[4];                                                                     // all four, after the swap
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    rs[a] = 0.f; rq[a] = 0.f; sa[a] = 0.f; sb[a] = 0.f;
+    sa[a] = 0.f; sb[a] = 0.f;
 #pragma unroll
     for (int b = 0; b < FB; ++b) { acc[a][b] = floatx4{0, 0, 0, 0}; tot[a][b] = floatx4{0, 0, 0, 0}; }
   }
@@ -429,15 +434,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
       if (LNF) {
+        // The two waves of a row block (same wm, wn = 0 / 1) read the same four x fragments: each accumulates the
+        // statistics of TWO of the four row tiles — wn = 0 tiles 0, 1; wn = 1 tiles 2, 3 — and they swap the sums before the
+        // epilogue (round 6: 16 instead of 32 v_dot2c per k-step and wave; a row's sums are made by one wave with exactly
+        // the instructions both made before: the same bits).  The wave's two tiles are picked with wave-uniform selects on
+        // the fragment registers (a branch, or an index, would put the sums into scratch memory).
         const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+        const half8_t xs0 = wn ? xv[ks][2] : xv[ks][0], xs1 = wn ? xv[ks][3] : xv[ks][1];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const half2_t h2 = {xv[ks][a][2 * e], xv[ks][a][2 * e + 1]};
-            rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
-            rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const half2_t h0 = {xs0[2 * e], xs0[2 * e + 1]}, h1 = {xs1[2 * e], xs1[2 * e + 1]};
+          rs[0] = __builtin_amdgcn_fdot2(h0, one2, rs[0], false);
+          rq[0] = __builtin_amdgcn_fdot2(h0, h0, rq[0], false);
+          rs[1] = __builtin_amdgcn_fdot2(h1, one2, rs[1], false);
+          rq[1] = __builtin_amdgcn_fdot2(h1, h1, rq[1], false);
         }
       }
 #pragma unroll
@@ -450,15 +460,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
   };
   auto compute = [&](int slot) { fetch(slot); mma(); };
   auto slice_end = [&]() {                // the skinny kernel's fixed-order reduction, one term at a time
+    if (LNF) {                            // (the wave's two row tiles: wn * 2 + 0 / 1)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (LNF) {
-        float pa = rs[a], pb = rq[a];
+      for (int aa = 0; aa < 2; ++aa) {
+        float pa = rs[aa], pb = rq[aa];
         pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
         pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
-        sa[a] += pa; sb[a] += pb;
-        rs[a] = 0.f; rq[a] = 0.f;
+        sal[aa] += pa; sbl[aa] += pb;
+        rs[aa] = 0.f; rq[aa] = 0.f;
       }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
 #pragma unroll
@@ -593,6 +606,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
   }
 
+  if (LNF) {
+    // every wave publishes the sums of its two row tiles; row tile a of this wave's row block was accumulated by the wave
+    // with wn = a >> 1 as its tile a & 1
+    float* xch = reinterpret_cast<float*>(dgb_smem);       // [wave][tile 0 / 1][row 16][sum, sum of squares]
+    if (g == 0) {
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        xch[((wave * 2 + aa) * 16 + i) * 2] = sal[aa];
+        xch[((wave * 2 + aa) * 16 + i) * 2 + 1] = sbl[aa];
+      }
+    }
+    DGB_BARRIER_LDS();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int owner = (wave & ~1) | (a >> 1);
+      sa[a] = xch[((owner * 2 + (a & 1)) * 16 + i) * 2];
+      sb[a] = xch[((owner * 2 + (a & 1)) * 16 + i) * 2 + 1];
+    }
+    DGB_BARRIER_LDS();                                     // the staging area below overwrites the exchange words
+  }
   // ---------------------------------- epilogue ----------------------------------
   char* ep = dgb_smem + wave * (64 * DGB_EP_STRIDE);       // this wave's 64-row x (16 FB)-column patch, fp16
   const int row0 = (rt0 + wm * 4) * 16;                    // first row / column of the wave's patch
