@@ -116,8 +116,9 @@ def load():
     lib.fw_model_run_capacity.argtypes = [vp]
     lib.fw_model_run_capacity.restype = i32
     lib.fw_dec_big_min_rows.restype = i32
-    lib.fw_dec_big_min_rows_of.restype = i32
-    lib.fw_dec_big_min_rows_of.argtypes = [i32, i32]
+    if hasattr(lib, "fw_dec_big_min_rows_of"):   # (absent from an older build loaded through FWAMD_LIB)
+        lib.fw_dec_big_min_rows_of.restype = i32
+        lib.fw_dec_big_min_rows_of.argtypes = [i32, i32]
     if hasattr(lib, "fw_flac_info"):
         lib.fw_flac_info.argtypes = [vp, i64, i32p, i32p, i32p, i64p]
         lib.fw_flac_decode.argtypes = [vp, i64, vp, i64, i64p, i32p]
@@ -172,7 +173,8 @@ def load():
     lib.fw_vad_forward.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.fw_vad_free.argtypes = [vp]
     lib.fw_vad_forward_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
-    lib.fw_vad_forward_audio_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
+    if hasattr(lib, "fw_vad_forward_audio_dev"):
+        lib.fw_vad_forward_audio_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
     lib.fw_vad_free.restype = None
     _lib = lib
     return lib

@@ -342,6 +342,8 @@ class Whisper:
     def dec_big_min_rows_of(self, role: int) -> int:
         """the same for one linear (0 qkv, 1 d x d, 2 ffn1, 3 ffn2) of THIS model's compute type: every linear has its own
         measured crossover (include/fwamd_test.h)"""
+        if not hasattr(self._lib, "fw_dec_big_min_rows_of"):      # an older build loaded through FWAMD_LIB (A/B of two builds)
+            return self.dec_big_min_rows()
         return int(self._lib.fw_dec_big_min_rows_of(int(role), 1 if self._compute_type_name == "int8_float16" else 0))
 
     def _replica_for(self, features: Optional[StorageView]) -> _Replica:

@@ -1970,12 +1970,13 @@ static int dec_linear_role(int N, int K) { return N == 3 * K ? 0 : (N >= 2560 ? 
 // profiles/r05_dec_linear_bench_call1.txt (round 5), profiles/r06_dec_linear_bench_*.txt (round 6: staggered 256 x 128).
 struct DecBigRule { int rows; int cfg; };
 static const DecBigRule DEC_BIG_RULES[4][2] = {
-    // (round 6, profiles/r06_dec_linear_bench_call9_reads_first.txt, us per launch register-streaming vs LDS-staged at 800 /
-    //  960 / 1 280 rows: d x d 10.0 / 11.8 / 15.8 vs 12.2 / 12.4 / 12.7, ffn1 35.2 / 41.5 / 52.9 vs 33.8 / 35.1 / 37.4 (128 x 128:
-    //  from 1 280 rows the 256 x 128 form is the same), ffn2 33.1 / 39.2 / 51.2 vs 33.4 / 33.7 / 36.8)
-    /* qkv  */ {{704, 2}, {1280, 0}},
-    /* dxd  */ {{1024, 1}, {1 << 30, 1}},
-    /* ffn1 */ {{800, 2}, {1280, 0}},
+    // (round 6, after the LayerNorm-statistics split, profiles/r06_dec_linear_bench_call11_crossovers.txt, us per launch
+    //  register-streaming vs LDS-staged: qkv 576 / 640 / 768 rows 20.9 / 23.0 / 26.6 vs 22.1 / 21.9 / 22.4 (128 x 128); ffn1 448 /
+    //  512 / 768 rows 21.8 / 24.3 / 33.3 vs 22.0 / 22.2 / 23.6 (128 x 128; 256 x 128 is the same from ~900 rows); ffn2 768 / 832
+    //  rows 32.3 / 37.0 vs 34.2 / 34.0 (128 x 64); d x d 1 024 / 1 120 rows 12.3 / 13.2 vs 12.8 / 12.9 (128 x 64))
+    /* qkv  */ {{640, 2}, {1280, 0}},
+    /* dxd  */ {{1088, 1}, {1 << 30, 1}},
+    /* ffn1 */ {{512, 2}, {1280, 0}},
     /* ffn2 */ {{832, 1}, {1 << 30, 1}},
 };
 static int dec_big_cfg_for(int R, int N, int K) {

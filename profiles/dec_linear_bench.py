@@ -16,6 +16,8 @@ VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)",
 if os.environ.get("DLB_VARIANTS"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["DLB_VARIANTS"].split(",")}
 SHAPES = [("qkv", 3840, 1280, 1), ("dxd", 1280, 1280, 0), ("ffn1", 5120, 1280, 1), ("ffn2", 1280, 5120, 0)]
+if os.environ.get("DLB_LNF") is not None:      # force the LayerNorm-folded form on / off for every shape (what the statistics cost)
+    SHAPES = [(n, N, K, int(os.environ["DLB_LNF"])) for n, N, K, _ in SHAPES]
 
 
 def main():
