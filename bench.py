@@ -66,12 +66,13 @@ def host_model(backend, cfg):
     return wm
 
 
-def synthetic_vad(device_index=0):
+def synthetic_vad(device_index=0, device=None):
     """A Silero-VAD-v6-shaped network (the initializer names / shapes of the reference's ONNX asset, faster_whisper/vad.py:
     288-351) with random weights, on the DEVICE path (csrc/vad.hip).  A random network answers ~ a constant; its output
     layer (a 1 x 1 convolution before the sigmoid) is rescaled so that digital silence and the bench's noise land on
     opposite sides of the threshold: logit' = gain * (logit - mid), mid / gain read off a calibration clip."""
     from faster_whisper_amd import vad as fvad
+    device = device or os.environ.get("FWAMD_BENCH_VAD_DEVICE", "cuda")      # ("cpu": the CPU test of this path)
     rng = np.random.default_rng(3)
     f = lambda *sh, scale=0.08: (rng.standard_normal(sh) * scale).astype(np.float32)   # noqa: E731
     w = {"encoder.feature_extractor.forward_basis_buffer": f(258, 1, 256, scale=0.05),
@@ -81,7 +82,7 @@ def synthetic_vad(device_index=0):
         w[f"encoder.conv_layers.{i}.weight"] = f(co, ci, 3)
         w[f"encoder.conv_layers.{i}.bias"] = f(co, scale=0.05)
     clip = np.concatenate([np.zeros(512 * 96, np.float32), synth_chunks(1, seed=5)[0][:512 * 96]])
-    p = np.asarray(fvad.SileroVADModel(weights=w, device="cuda", device_index=device_index)(clip), dtype=np.float64)
+    p = np.asarray(fvad.SileroVADModel(weights=w, device=device, device_index=device_index)(clip), dtype=np.float64)
     z = np.log(p / (1.0 - p))
     z_sil, z_noise = float(np.median(z[8:88])), float(np.percentile(z[104:184], 2))
     mid, gain = 0.5 * (z_sil + z_noise), 8.0 / max(1e-4, abs(z_noise - z_sil))
@@ -89,7 +90,7 @@ def synthetic_vad(device_index=0):
         gain = -gain
     w["decoder.conv1d.weight"] = (w["decoder.conv1d.weight"] * gain).astype(np.float32)
     w["decoder.conv1d.bias"] = (w["decoder.conv1d.bias"] * gain - gain * mid).astype(np.float32)
-    return fvad.SileroVADModel(weights=w, device="cuda", device_index=device_index)
+    return fvad.SileroVADModel(weights=w, device=device, device_index=device_index)
 
 
 def pipeline_rtf(backend, cfg, n_chunks, batch, beam, new_tokens, seed=0, shard=False, sync=None,

@@ -782,6 +782,9 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_i8_kernel(
 // so every weight byte is requested exactly once per 80 rows.
 // I8: int8 operands (v_mfma_i32_16x16x64_i8, 64 elements per 16-byte fragment) with per-row scales.
 // ------------------------------------------------------------------------------------
+// (the folded form with RT = 5 sits at 172 registers — one allocation granule above the 168 that let a third wave per SIMD in;
+//  __launch_bounds__(256, 3) gets there with 8 spilled values and is 11 % SLOWER: 2.87 vs 2.53 ms per batch in one A/B of
+//  three builds on one box, profiles/r06_ab_logits_split.jsonl)
 template <bool I8, bool LNF, bool F32, int RT, int NT, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
     const void* __restrict__ xfv, const float* __restrict__ x_scale, const void* __restrict__ Wfv,
@@ -799,7 +802,17 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
   const int b8 = blockIdx.x >> 3;
   const int cgrp = (b8 / n_rg) * 8 + (blockIdx.x & 7), rgrp = b8 % n_rg;
   const int rt0 = (rgrp * WM + wm) * RT, ct0 = (cgrp * WN + wn) * NT;
-  if (rt0 >= n_rt || ct0 >= n_ct) return;     // whole waves leave: there is no barrier in this kernel
+  // SPLIT (round 6): the four waves of a workgroup (WM = 1: the same row tiles, four column groups) each accumulate the
+  // folded LayerNorm's statistics of ONE or TWO of the row tiles — wave wn: tile wn, wave 0 also tile 4 — instead of all
+  // RT of them each, and swap the sums through LDS before the epilogue: 8-16 instead of 40 v_dot2c per k-step and wave
+  // beside 10 MFMAs (measured: 2.60 -> 2.53 ms per batch — the kernel waits on its weight stream, not on its vector
+  // instructions; kept because it is free).  A row's sums are made by one
+  // wave with the instructions every wave used before: the same bits.  The swap needs all four waves at ONE barrier, so the
+  // waves of the padded last column groups stay (clamped loads, nothing stored) instead of leaving.
+  constexpr bool SPLIT = LNF && WM == 1 && WN == 4 && RT >= 4;
+  __shared__ float xst[SPLIT ? RT : 1][16][2];
+  if (rt0 >= n_rt) return;                    // (the whole workgroup: WM = 1 when SPLIT)
+  if (!SPLIT && ct0 >= n_ct) return;          // whole waves leave: there is no barrier in the un-split kernel
   const int KS = K / (I8 ? 64 : 32);
   const intx4* wp[NT];
   const intx4* xp[RT];
@@ -846,7 +859,7 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
                                                                     __builtin_bit_cast(half8_t, f.x[j][a]), accf[a][b],
                                                                     0, 0, 0);
           }
-          if (LNF) {
+          if (LNF && !SPLIT) {
             const half8_t xv = __builtin_bit_cast(half8_t, f.x[j][a]);
             const half2_t one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
@@ -854,6 +867,28 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
               const half2_t h2 = {xv[2 * e], xv[2 * e + 1]};
               rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
               rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
+            }
+          }
+        }
+        if (SPLIT) {
+          // this wave's tile wn, picked with wave-uniform selects on the fragment registers (an index or a branch around an
+          // array element would put the sums into scratch memory); sums in rs[0] / rq[0]; wave 0: also tile 4 in rs[1] / rq[1]
+          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+          const intx4 xsel = wn == 0 ? f.x[j][0] : (wn == 1 ? f.x[j][1] : (wn == 2 ? f.x[j][2] : f.x[j][RT > 3 ? 3 : 0]));
+          const half8_t xv = __builtin_bit_cast(half8_t, xsel);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2_t h2 = {xv[2 * e], xv[2 * e + 1]};
+            rs[0] = __builtin_amdgcn_fdot2(h2, one2, rs[0], false);
+            rq[0] = __builtin_amdgcn_fdot2(h2, h2, rq[0], false);
+          }
+          if (RT > 4 && wn == 0) {
+            const half8_t xw = __builtin_bit_cast(half8_t, f.x[j][RT > 4 ? 4 : 0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h2 = {xw[2 * e], xw[2 * e + 1]};
+              rs[1] = __builtin_amdgcn_fdot2(h2, one2, rs[1], false);
+              rq[1] = __builtin_amdgcn_fdot2(h2, h2, rq[1], false);
             }
           }
         }
@@ -868,13 +903,29 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
     load(fa, ks0 + 2 * CH);
     compute(fb, ks0 + CH);
   }
+  if (SPLIT) {   // publish this wave's tile(s): row i of a tile, the 4 k-octet lanes hold the partial sums over the whole K
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1 && !(RT > 4 && wn == 0)) break;
+      float sa = rs[q], sb = rq[q];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      if (g == 0) { xst[q == 0 ? wn : 4][i][0] = sa; xst[q == 0 ? wn : 4][i][1] = sb; }
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int a = 0; a < RT; ++a) {
     float mu = 0.f, rstd = 1.f;
     if (LNF) {   // row i of tile a: the 4 k-octet lanes hold the partial sums over the whole K
-      float sa = rs[a], sb = rq[a];
-      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      float sa, sb;
+      if (SPLIT) {
+        sa = xst[a][i][0]; sb = xst[a][i][1];
+      } else {
+        sa = rs[a]; sb = rq[a];
+        sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      }
       mu = sa / (float)K;
       rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
     }

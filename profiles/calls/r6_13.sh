@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round 6, GPU call 13: the whole -m gpu suite and smoke() on the final kernels (crossovers of call 11).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r06
+mkdir -p "$OUT"
+cd "$R"
+t0=$(date +%s)
+timeout 1500 python -m pytest tests -m gpu -q -s > "$OUT/pytest_gpu.log" 2>&1
+echo "pytest rc=$? $(( $(date +%s) - t0 ))s"; tail -5 "$OUT/pytest_gpu.log" | cut -c1-300
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+echo "smoke rc=$?"; tail -2 "$OUT/smoke.log"
