@@ -1924,6 +1924,8 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
 //   cfg 2: 2 x 2 waves, 128 x 128, 1 k-step per stage, 4 stages (64 KB)
 //   cfg 3: cfg 0's tile with two STAGGERED wave groups, 1 k-step per stage, ring of 6 (144 KB), 4 k-steps in flight (round 6)
 //   cfg 4: the same with a ring of 5 (120 KB), 3 k-steps in flight
+//   cfg 5 / 6: cfg 1's tile with TWO k-steps per stage, ring of 3 (72 KB) / 4 (96 KB): half the waits and barriers per k-step
+//   cfg 7: cfg 2's tile with two k-steps per stage, ring of 3 (96 KB: one workgroup per CU)
 // (measured next to 256 x 64, 128 x 256, 8 waves on 128 x 128, deeper rings, two k-steps per barrier, LDS reads
 //  software-pipelined under the MFMAs, L2 touch-ahead: profiles/r03_dec_linear_bench.txt — none better)
 template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST, bool STG>
@@ -1968,6 +1970,9 @@ int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t*
     case 2: return big_cfg<2, 2, 4, 1, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 3: return big_cfg<4, 2, 4, 1, 6, true>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 4: return big_cfg<4, 2, 4, 1, 5, true>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 5: return big_cfg<2, 2, 2, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 6: return big_cfg<2, 2, 2, 2, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
+    case 7: return big_cfg<2, 2, 4, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     default: return -1;
   }
 }
@@ -2005,7 +2010,7 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 26: frag_variant<8, 1, 2, 6>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 21: frag_variant<4, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 22: frag_variant<8, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
-    case 10: case 11: case 12: case 13: case 14:
+    case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:
       return launch_dec_gemm_big(st, variant - 10, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr,
                                  nullptr, 0, out, N, nullptr, R, N, K, 0);
     default: return -1;
@@ -2028,7 +2033,7 @@ static const DecBigRule DEC_BIG_RULES[4][2] = {
     /* qkv  */ {{640, 2}, {1280, 0}},
     /* dxd  */ {{1088, 1}, {1 << 30, 1}},
     /* ffn1 */ {{512, 2}, {1280, 0}},
-    /* ffn2 */ {{832, 1}, {1 << 30, 1}},
+    /* ffn2 */ {{832, 6}, {1 << 30, 6}},   // (two k-steps per stage, ring of 4: 36.5 -> 35.1 us at 1 280 rows, r06_dec_linear_bench_call15_kc2.txt)
 };
 static int dec_big_cfg_for(int R, int N, int K) {
   const DecBigRule* r = DEC_BIG_RULES[dec_linear_role(N, K)];
