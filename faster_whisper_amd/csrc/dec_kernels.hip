@@ -333,7 +333,7 @@ static __device__ __forceinline__ void wait_vmcnt() {
 // workgroup barrier WITH the LDS fence (plain data exchange through LDS, outside the K loop)
 #define DGB_BARRIER_LDS() __syncthreads()
 
-template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST, bool STG = false>
+template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
 __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     const half_t* __restrict__ xf, const half_t* __restrict__ Wf, const half_t* __restrict__ bias,
     const float* __restrict__ s1, const float* __restrict__ cf, const half_t* __restrict__ res, int ldr,
@@ -481,130 +481,45 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     }
   };
 
-  if constexpr (STG) {
-    // ---- round 6: two STAGGERED wave groups (waves w and w + 4 share a SIMD; group = wave >> 2) ----
-    // The lockstep loop below serialises, on every SIMD, [both waves blocked in their global_load_lds issues: the CU's
-    // L2 -> LDS path takes ~28 cycles per 1 KB piece whoever issues it] and [both waves' MFMAs].  Here a k-step is two
-    // half-phases separated by barriers A and B; in each, one group ISSUES its share of the stage LEAD k-steps ahead
-    // while the other group MULTIPLIES, so a wave's DMA issue time runs beside its SIMD partner's MFMAs (the structure
-    // of gemm.hip's K loop).  Group 1 runs one multiply behind group 0:
-    //     group 0, k-step c:  A(c) | issue(c + LEAD), wait own pieces of c | B(c) | multiply(c)
-    //     group 1, k-step c:  A(c) | multiply(c - 1), wait own pieces of c | B(c) | issue(c + LEAD)
-    //   RAW: stage c is complete for everybody at B(c) (both groups' counted waits precede it); group 1 reads it after
-    //        A(c + 1) > B(c).   WAR: stage c + LEAD lands in the slot of stage c + LEAD - NST = c - 2 (LEAD = NST - 2),
-    //        last read by group 1 between A(c - 1) and B(c - 1) and by group 0 before A(c - 1): both before A(c).
-    // Same MFMA chains per wave, same slice order, same epilogue as the lockstep form: the same bits.
-    static_assert(NW == 8 && KC == 1 && NST >= 5, "staggered form: 8 waves, one k-step per stage, ring of >= 5");
-    constexpr int LEAD = NST - 2;
-    const int grp = wave >> 2;
+  // (Round 6 built the encoder GEMM's recipe here too — two wave groups staggered by half a k-step, one issuing the DMA of the
+  //  stage four k-steps ahead while the other multiplies, ring of 6 / 5 — bit-identical and 10 % SLOWER (39.9 vs 35.9 us for qkv at
+  //  1 280 rows): the stamps of profiles/ubench/dec_big_timeline.hip show a group's DMA issue at 160-190 cycles of a k-step and
+  //  its multiply segment at ~1 050, and the stagger doubles the barriers.  Removed; the code is in the history: commit 1d52bf7,
+  //  profiles/r06_dec_linear_bench_call2_stagger.txt.)
 #pragma unroll
-    for (int c0 = 0; c0 < LEAD; ++c0) issue(c0, c0);
-    int to_slice = ch_per_slice;
-    const int n_steady = nch - LEAD;          // k-steps that still issue (the launcher guarantees nch >= NST)
-    auto next = [](int sl) { return (sl + 1 == NST) ? 0 : sl + 1; };
-    if (grp == 0) {
-      int slot = 0, fill = LEAD;
-      for (int c = 0; c < n_steady; ++c) {
-        DGB_TL(0);
-        DGB_BARRIER();                        // A(c)
-        DGB_TL(1);
-        issue(c + LEAD, fill);
-        DGB_TL(2);
-        wait_vmcnt<LEAD * PPW>();             // own pieces of stage c (LEAD younger stages stay in flight)
-        DGB_BARRIER();                        // B(c)
-        DGB_TL(3);
-        compute(slot);
-        DGB_TL(5);
-        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-        slot = next(slot); fill = next(fill);
-      }
-      auto tail0 = [&](auto jc) {             // k-step n_steady + j: nothing left to issue
-        constexpr int j = decltype(jc)::value;
-        DGB_BARRIER();
-        wait_vmcnt<(LEAD - 1 - j) * PPW>();
-        DGB_BARRIER();
-        compute(slot);
-        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-        slot = next(slot);
-      };
-      tail0(std::integral_constant<int, 0>{});
-      tail0(std::integral_constant<int, 1>{});
-      tail0(std::integral_constant<int, 2>{});
-      if constexpr (LEAD > 3) tail0(std::integral_constant<int, 3>{});
-    } else {
-      int slot = 0, fill = LEAD;              // slot: the stage group 1 multiplies next (one behind group 0)
-      DGB_BARRIER();                          // A(0): nothing to multiply yet
-      wait_vmcnt<(LEAD - 1) * PPW>();
-      DGB_BARRIER();                          // B(0)
-      issue(LEAD, fill);
-      fill = next(fill);
-      for (int c = 1; c < n_steady; ++c) {
-        DGB_TL(0);
-        DGB_BARRIER();                        // A(c)
-        DGB_TL(1);
-        compute(slot);                        // stage c - 1
-        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-        DGB_TL(2);
-        wait_vmcnt<(LEAD - 1) * PPW>();       // own pieces of stage c
-        DGB_BARRIER();                        // B(c)
-        DGB_TL(3);
-        issue(c + LEAD, fill);
-        DGB_TL(5);
-        slot = next(slot); fill = next(fill);
-      }
-      auto tail1 = [&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        DGB_BARRIER();
-        compute(slot);
-        if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-        slot = next(slot);
-        wait_vmcnt<(LEAD - 1 - j) * PPW>();
-        DGB_BARRIER();
-      };
-      tail1(std::integral_constant<int, 0>{});
-      tail1(std::integral_constant<int, 1>{});
-      tail1(std::integral_constant<int, 2>{});
-      if constexpr (LEAD > 3) tail1(std::integral_constant<int, 3>{});
-      compute(slot);                          // the last stage, beside group 0's wait at the barrier below
-      if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-    }
-    DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
-  } else {
-#pragma unroll
-    for (int c0 = 0; c0 < NST - 1; ++c0) issue(c0, c0);
-    int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
-    int to_slice = ch_per_slice;
-    const int n_steady = nch - (NST - 1);
-    // steady state: stages c .. c + NST - 2 are in flight; wait until only the NST - 2 younger ones are
-    for (int c = 0; c < n_steady; ++c) {
-      DGB_TL(0);
-      wait_vmcnt<(NST - 2) * PPW>();
-      DGB_TL(1);
-      DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
-      DGB_TL(2);
-      // the LDS reads of stage c leave BEFORE the DMA of stage c + NST - 1 is issued (round 6): the ~270 cycles a wave spends
-      // issuing its global_load_lds pieces now run under the latency of its own 8 KB read burst instead of in front of it
-      // (profiles/r06_dec_big_timeline.txt: barrier | issue 267-478 | reads + lgkmcnt(0) wait | MFMAs, all in series)
-      fetch(slot);
-      DGB_TL(3);
-      issue(c + NST - 1, fill);             // ... whose slot (stage c - 1's) is the one refilled now
-      mma();
-      DGB_TL(5);
-      if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-      fill = slot;
-      slot = (slot + 1 == NST) ? 0 : slot + 1;
-    }
-    // tail: nothing left to issue; the queue is drained once
-    wait_vmcnt<0>();
-  #pragma unroll 1
-    for (int c = n_steady; c < nch; ++c) {
-      DGB_BARRIER();
-      compute(slot);
-      if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
-      slot = (slot + 1 == NST) ? 0 : slot + 1;
-    }
-    DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
+  for (int c0 = 0; c0 < NST - 1; ++c0) issue(c0, c0);
+  int slot = 0, fill = NST - 1;           // slot of stage c; slot refilled in iteration c (= slot of stage c - 1)
+  int to_slice = ch_per_slice;
+  const int n_steady = nch - (NST - 1);
+  // steady state: stages c .. c + NST - 2 are in flight; wait until only the NST - 2 younger ones are
+  for (int c = 0; c < n_steady; ++c) {
+    DGB_TL(0);
+    wait_vmcnt<(NST - 2) * PPW>();
+    DGB_TL(1);
+    DGB_BARRIER();   // stage c has landed for every wave, and every wave has finished reading stage c - 1 ...
+    DGB_TL(2);
+    // the LDS reads of stage c leave BEFORE the DMA of stage c + NST - 1 is issued (round 6): the ~270 cycles a wave spends
+    // issuing its global_load_lds pieces now run under the latency of its own 8 KB read burst instead of in front of it
+    // (profiles/r06_dec_big_timeline.txt: barrier | issue 267-478 | reads + lgkmcnt(0) wait | MFMAs, all in series)
+    fetch(slot);
+    DGB_TL(3);
+    issue(c + NST - 1, fill);             // ... whose slot (stage c - 1's) is the one refilled now
+    mma();
+    DGB_TL(5);
+    if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+    fill = slot;
+    slot = (slot + 1 == NST) ? 0 : slot + 1;
   }
+  // tail: nothing left to issue; the queue is drained once
+  wait_vmcnt<0>();
+#pragma unroll 1
+  for (int c = n_steady; c < nch; ++c) {
+    DGB_BARRIER();
+    compute(slot);
+    if (--to_slice == 0) { to_slice = ch_per_slice; slice_end(); }
+    slot = (slot + 1 == NST) ? 0 : slot + 1;
+  }
+  DGB_BARRIER();     // every wave is done with the ring: it becomes the epilogue's staging area
 
   if (LNF) {
     // every wave publishes the sums of its two row tiles; row tile a of this wave's row block was accumulated by the wave
@@ -1922,13 +1837,13 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
 //          workgroups per CU) — the linears with 1280 columns (out / cross-q / cross-out, ffn2), which a wider tile
 //          cannot spread over the chip
 //   cfg 2: 2 x 2 waves, 128 x 128, 1 k-step per stage, 4 stages (64 KB)
-//   cfg 3: cfg 0's tile with two STAGGERED wave groups, 1 k-step per stage, ring of 6 (144 KB), 4 k-steps in flight (round 6)
-//   cfg 4: the same with a ring of 5 (120 KB), 3 k-steps in flight
-//   cfg 5 / 6: cfg 1's tile with TWO k-steps per stage, ring of 3 (72 KB) / 4 (96 KB): half the waits and barriers per k-step
-//   cfg 7: cfg 2's tile with two k-steps per stage, ring of 3 (96 KB: one workgroup per CU)
+//   cfg 6: cfg 1's tile with TWO k-steps per stage, ring of 4 (96 KB): half the waits and barriers per k-step — ffn2 (K = 5 120:
+//          160 k-steps), 36.5 -> 35.1 us at 1 280 rows
+//   (cfg 3 / 4, the staggered forms of cfg 0, cfg 5 = cfg 6 with a ring of 3 and cfg 7 = cfg 2 with two k-steps per stage were
+//    measured in round 6 and removed: profiles/r06_dec_linear_bench_call2_stagger.txt, _call15_kc2.txt, _call16_cfg7.txt)
 // (measured next to 256 x 64, 128 x 256, 8 waves on 128 x 128, deeper rings, two k-steps per barrier, LDS reads
 //  software-pipelined under the MFMAs, L2 touch-ahead: profiles/r03_dec_linear_bench.txt — none better)
-template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST, bool STG>
+template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
 static int big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
   constexpr int lds = (4 * WM + FB * WN) * KC * 1024 * NST;
@@ -1938,17 +1853,17 @@ static int big_go(hipStream_t st, const half_t* xf, const half_t* Wf, const half
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST, STG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -1;
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int nMt = ((R + 15) / 16 + 4 * WM - 1) / (4 * WM), nNt = (N / 16 + FB * WN - 1) / (FB * WN);
-  dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST, STG><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out,
+  dec_gemm_big_kernel<LNF, S, WM, WN, FB, KC, NST><<<nMt * nNt, WM * WN * 64, lds, st>>>(xf, Wf, bias, s1, cf, res, ldr, out,
                                                                                            ldo, out_frag, R, N, K, act, nNt);
   return hipPeekAtLastError() == hipSuccess ? 0 : -1;
 }
-template <int WM, int WN, int FB, int KC, int NST, bool STG = false>
+template <int WM, int WN, int FB, int KC, int NST>
 static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const half_t* bias, const float* s1, const float* cf,
                    const half_t* res, int ldr, half_t* out, int ldo, half_t* out_frag, int R, int N, int K, int act) {
   if (K % 32 != 0 || N % 32 != 0 || R < 1) return -1;
@@ -1956,7 +1871,7 @@ static int big_cfg(hipStream_t st, const half_t* xf, const half_t* Wf, const hal
   const int KS = K / 32;
   if (KS % S != 0 || (KS / S) % KC != 0 || KS / KC < NST) return -1;
   if ((ldo % 8) || (res && (ldr % 8))) return -1;   // 16-byte row segments
-#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, FB, KC, NST, STG>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
+#define DGB(LNF_, S_) big_go<LNF_, S_, WM, WN, FB, KC, NST>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act)
   if (s1) return S == 8 ? DGB(true, 8) : DGB(true, 4);
   return S == 8 ? DGB(false, 8) : DGB(false, 4);
 #undef DGB
@@ -1968,11 +1883,7 @@ int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t*
     case 0: return big_cfg<4, 2, 4, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 1: return big_cfg<2, 2, 2, 1, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 2: return big_cfg<2, 2, 4, 1, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 3: return big_cfg<4, 2, 4, 1, 6, true>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 4: return big_cfg<4, 2, 4, 1, 5, true>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 5: return big_cfg<2, 2, 2, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 6: return big_cfg<2, 2, 2, 2, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 7: return big_cfg<2, 2, 4, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     default: return -1;
   }
 }
@@ -2010,7 +1921,7 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 26: frag_variant<8, 1, 2, 6>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 21: frag_variant<4, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 22: frag_variant<8, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
-    case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:
+    case 10: case 11: case 12: case 16:
       return launch_dec_gemm_big(st, variant - 10, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr,
                                  nullptr, 0, out, N, nullptr, R, N, K, 0);
     default: return -1;

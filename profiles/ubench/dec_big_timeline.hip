@@ -1,11 +1,9 @@
 // Diagnostic (gfx950): cycle stamps inside the K loop of dec_gemm_big_kernel (the LDS-staged decoder linear of merged
 // decode runs) — where do the ~1 800 cycles of a k-step go?  Waves 0 and 4 (the two waves of one SIMD) of workgroup 0
 // record (slot, cycle) for their first 192 stamps; the slots are the DGB_TL(n) marks in csrc/dec_kernels.hip:
-//   lockstep loop (cfg 0 / 1 / 2):  0 top | 1 after the counted vmcnt wait | 2 after the barrier | 3 after the DMA issue
-//                                   | 4 after the LDS reads (before the first MFMA) | 5 after the MFMAs
-//   staggered loop (cfg 3 / 4):     group 0: 0 top | 1 after barrier A | 2 after issue | 3 after wait + barrier B | 4 | 5
-//                                   group 1: 0 top | 1 after barrier A | 4 (reads done) | 2 after multiply | 3 after wait +
-//                                   barrier B | 5 after issue
+//   lockstep loop (cfg 0 / 1 / 2):  0 top | 1 after the counted vmcnt wait | 2 after the barrier | 3 after the LDS-read issue
+//                                   | (DMA issue) | 4 before the first MFMA | 5 after the MFMAs
+//   (the staggered form of round 6 — commit 1d52bf7 — had its own marks; its timeline is in profiles/r06_dec_big_timeline.txt)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../faster_whisper_amd/csrc -I../../include dec_big_timeline.hip -o /tmp/dbt && /tmp/dbt
 #include <hip/hip_runtime.h>
 #define DGB_NTL 192
@@ -72,11 +70,10 @@ static void run(int cfg, int R, int N, int K, bool lnf) {
 int main() {
   for (int R : {1280}) {
     run(0, R, 3840, 1280, true);    // qkv, 256 x 128 lockstep (2 k-steps per stage, ring of 3)
-    run(3, R, 3840, 1280, true);    // the staggered form (1 k-step per stage, ring of 6)
     run(2, R, 3840, 1280, true);    // 128 x 128, 4 waves (1 k-step per stage, ring of 4)
     run(1, R, 1280, 1280, false);   // d x d, 128 x 64
     run(0, R, 5120, 1280, true);    // ffn1
-    run(3, R, 5120, 1280, true);
+    run(6, R, 1280, 5120, false);   // ffn2, 128 x 64 with two k-steps per stage
   }
   return 0;
 }
