@@ -69,27 +69,6 @@ static __device__ __forceinline__ void dec_ln_stats(float sa, float sb, int K, f
   const float var = ex2 - mu * mu;
   rstd = rsqrtf(fmaxf(var, 0.f) + 1e-5f);
 }
-// The folded LayerNorm's row statistics on the MATRIX pipe (round 6).  A linear with the LayerNorm folded into its weights needs
-// sum(x) and sum(x^2) of every input row over K.  Until round 6 every kernel form made them with 8 v_dot2c per x fragment
-// beside its MFMAs — 15-17 % of a merged run's qkv / cross-q / ffn1 launch (profiles/r06_dec_linear_bench_call12_lnf_cost.txt),
-// on the vector pipe that was the busier one.  The x fragment is already an MFMA operand: ones x X^T gives the row sums (row i's
-// sum in every element of lane (i, g)) and X x X^T the Gram matrix whose diagonal holds the sums of squares — two MFMAs per
-// fragment on a matrix pipe that is 15-25 % busy.  Every kernel form (register-streaming, LDS-staged, vocabulary projection) goes
-// through these two functions, one accumulator chain per K slice in k order, slice partials added in slice order from 0.0f: a
-// merged run still returns a solo run's bits.
-static __device__ __forceinline__ void ln_stat_step(floatx4& s1, floatx4& s2, const half8_t x) {
-  const half8_t ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
-  s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, x, s1, 0, 0, 0);
-  s2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, x, s2, 0, 0, 0);
-}
-// lane (i = lane & 15, g = lane >> 4) holds D[4 g + e][i]: the diagonal element of row i sits in lane (i, i >> 2) at e = i & 3
-static __device__ __forceinline__ void ln_stat_read(const floatx4 s1, const floatx4 s2, int lane, float& sum, float& sq) {
-  const int i = lane & 15, e = i & 3;
-  sum = s1[0];
-  const float d = e == 0 ? s2[0] : (e == 1 ? s2[1] : (e == 2 ? s2[2] : s2[3]));
-  sq = __shfl(d, ((i >> 2) << 4) + i, 64);
-}
-
 template <bool LNF>
 static __device__ __forceinline__ half4_t dec_epilogue4(const floatx4 v, float mu, float rstd,
                                                         const float* __restrict__ s1, const float* __restrict__ cf,
@@ -192,10 +171,10 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
   int nks = KS - ks0;
   if (nks > per) nks = per;
   floatx4 acc[RT][NT];
-  floatx4 st1[RT], st2[RT];               // LNF: the row tiles' statistics (ln_stat_step)
+  float rs[RT], rq[RT];
 #pragma unroll
   for (int a = 0; a < RT; ++a) {
-    st1[a] = floatx4{0, 0, 0, 0}; st2[a] = floatx4{0, 0, 0, 0};
+    rs[a] = 0.f; rq[a] = 0.f;
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = floatx4{0, 0, 0, 0};
   }
@@ -248,7 +227,15 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
 #pragma unroll
             for (int b = 0; b < NT; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[b][j], xv[a][j], acc[a][b], 0, 0, 0);
-            if (LNF) ln_stat_step(st1[a], st2[a], xv[a][j]);
+            if (LNF) {
+              const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const half2_t h2 = {xv[a][j][2 * e], xv[a][j][2 * e + 1]};
+                rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
+                rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
+              }
+            }
           }
         }
       }
@@ -256,9 +243,10 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_frag_kernel(
   }
 #pragma unroll
   for (int a = 0; a < RT; ++a) {
-    if (LNF) {   // row i's statistics over this wave's K slice; the waves' partials are added in wave order below
-      float sa, sb;
-      ln_stat_read(st1[a], st2[a], lane, sa, sb);
+    if (LNF) {   // row i's statistics: the 4 k-octet lanes of the row, then the waves
+      float sa = rs[a], sb = rq[a];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
       if (g == 0) { red_s[wave][a][i][0] = sa; red_s[wave][a][i][1] = sb; }
     }
 #pragma unroll
@@ -411,8 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
 
   static_assert(!LNF || WN == 2, "the LayerNorm statistics are shared by the TWO waves of a row block");
   floatx4 acc[4][FB], tot[4][FB];
-  floatx4 m1[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}}, m2[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};   // ln_stat_step, per slice
-  float sal[2] = {0.f, 0.f}, sbl[2] = {0.f, 0.f};                                           // this wave's two row tiles
+  float rs[2] = {0.f, 0.f}, rq[2] = {0.f, 0.f}, sal[2] = {0.f, 0.f}, sbl[2] = {0.f, 0.f};   // this wave's two row tiles
   float sa[4], sb[4];                                                                     // all four, after the swap
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -452,9 +439,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
         // epilogue (round 6: 16 instead of 32 v_dot2c per k-step and wave; a row's sums are made by one wave with exactly
         // the instructions both made before: the same bits).  The wave's two tiles are picked with wave-uniform selects on
         // the fragment registers (a branch, or an index, would put the sums into scratch memory).
+        const half2_t one2 = {(half_t)1.f, (half_t)1.f};
         const half8_t xs0 = wn ? xv[ks][2] : xv[ks][0], xs1 = wn ? xv[ks][3] : xv[ks][1];
-        ln_stat_step(m1[0], m2[0], xs0);
-        ln_stat_step(m1[1], m2[1], xs1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2_t h0 = {xs0[2 * e], xs0[2 * e + 1]}, h1 = {xs1[2 * e], xs1[2 * e + 1]};
+          rs[0] = __builtin_amdgcn_fdot2(h0, one2, rs[0], false);
+          rq[0] = __builtin_amdgcn_fdot2(h0, h0, rq[0], false);
+          rs[1] = __builtin_amdgcn_fdot2(h1, one2, rs[1], false);
+          rq[1] = __builtin_amdgcn_fdot2(h1, h1, rq[1], false);
+        }
       }
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
@@ -469,10 +463,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void dec_gemm_big_kernel(
     if (LNF) {                            // (the wave's two row tiles: wn * 2 + 0 / 1)
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
-        float pa, pb;
-        ln_stat_read(m1[aa], m2[aa], lane, pa, pb);
+        float pa = rs[aa], pb = rq[aa];
+        pa += __shfl_xor(pa, 16, 64); pa += __shfl_xor(pa, 32, 64);
+        pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
         sal[aa] += pa; sbl[aa] += pb;
-        m1[aa] = floatx4{0, 0, 0, 0}; m2[aa] = floatx4{0, 0, 0, 0};
+        rs[aa] = 0.f; rq[aa] = 0.f;
       }
     }
 #pragma unroll
@@ -748,12 +743,10 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
   }
   floatx4 accf[RT][NT];
   intx4 acci[RT][NT];
-  constexpr int NSTAT = LNF ? (WM == 1 && WN == 4 && RT >= 4 ? 2 : RT) : 1;   // row tiles whose statistics this wave accumulates
-  floatx4 st1[NSTAT], st2[NSTAT];
-#pragma unroll
-  for (int a = 0; a < NSTAT; ++a) { st1[a] = floatx4{0, 0, 0, 0}; st2[a] = floatx4{0, 0, 0, 0}; }
+  float rs[RT], rq[RT];
 #pragma unroll
   for (int a = 0; a < RT; ++a) {
+    rs[a] = 0.f; rq[a] = 0.f;
 #pragma unroll
     for (int b = 0; b < NT; ++b) { accf[a][b] = floatx4{0, 0, 0, 0}; acci[a][b] = intx4{0, 0, 0, 0}; }
   }
@@ -781,14 +774,38 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
                                                                     __builtin_bit_cast(half8_t, f.x[j][a]), accf[a][b],
                                                                     0, 0, 0);
           }
-          if (LNF && !SPLIT) ln_stat_step(st1[a < NSTAT ? a : 0], st2[a < NSTAT ? a : 0], __builtin_bit_cast(half8_t, f.x[j][a]));
+          if (LNF && !SPLIT) {
+            const half8_t xv = __builtin_bit_cast(half8_t, f.x[j][a]);
+            const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h2 = {xv[2 * e], xv[2 * e + 1]};
+              rs[a] = __builtin_amdgcn_fdot2(h2, one2, rs[a], false);
+              rq[a] = __builtin_amdgcn_fdot2(h2, h2, rq[a], false);
+            }
+          }
         }
         if (SPLIT) {
           // this wave's tile wn, picked with wave-uniform selects on the fragment registers (an index or a branch around an
           // array element would put the sums into scratch memory); sums in rs[0] / rq[0]; wave 0: also tile 4 in rs[1] / rq[1]
+          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
           const intx4 xsel = wn == 0 ? f.x[j][0] : (wn == 1 ? f.x[j][1] : (wn == 2 ? f.x[j][2] : f.x[j][RT > 3 ? 3 : 0]));
-          ln_stat_step(st1[0], st2[0], __builtin_bit_cast(half8_t, xsel));
-          if (RT > 4 && wn == 0) ln_stat_step(st1[NSTAT > 1 ? 1 : 0], st2[NSTAT > 1 ? 1 : 0], __builtin_bit_cast(half8_t, f.x[j][RT > 4 ? 4 : 0]));
+          const half8_t xv = __builtin_bit_cast(half8_t, xsel);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2_t h2 = {xv[2 * e], xv[2 * e + 1]};
+            rs[0] = __builtin_amdgcn_fdot2(h2, one2, rs[0], false);
+            rq[0] = __builtin_amdgcn_fdot2(h2, h2, rq[0], false);
+          }
+          if (RT > 4 && wn == 0) {
+            const half8_t xw = __builtin_bit_cast(half8_t, f.x[j][RT > 4 ? 4 : 0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h2 = {xw[2 * e], xw[2 * e + 1]};
+              rs[1] = __builtin_amdgcn_fdot2(h2, one2, rs[1], false);
+              rq[1] = __builtin_amdgcn_fdot2(h2, h2, rq[1], false);
+            }
+          }
         }
       }
     }
@@ -804,9 +821,10 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
   if (SPLIT) {   // publish this wave's tile(s): row i of a tile, the 4 k-octet lanes hold the partial sums over the whole K
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      float sa, sb;                         // (every lane takes part in ln_stat_read's shuffle: no early exit before it)
-      ln_stat_read(st1[q < NSTAT ? q : 0], st2[q < NSTAT ? q : 0], lane, sa, sb);
       if (q == 1 && !(RT > 4 && wn == 0)) break;
+      float sa = rs[q], sb = rq[q];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
       if (g == 0) { xst[q == 0 ? wn : 4][i][0] = sa; xst[q == 0 ? wn : 4][i][1] = sb; }
     }
     __syncthreads();
@@ -819,7 +837,9 @@ __global__ __launch_bounds__(WM * WN * 64) void dec_gemm_wave_kernel(
       if (SPLIT) {
         sa = xst[a][i][0]; sb = xst[a][i][1];
       } else {
-        ln_stat_read(st1[a < NSTAT ? a : 0], st2[a < NSTAT ? a : 0], lane, sa, sb);
+        sa = rs[a]; sb = rq[a];
+        sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
       }
       mu = sa / (float)K;
       rstd = rsqrtf(fmaxf(sb / (float)K - mu * mu, 0.f) + 1e-5f);
