@@ -1837,10 +1837,12 @@ static void frag_go(hipStream_t st, int waves, const half_t* xf, const half_t* W
 //          workgroups per CU) — the linears with 1280 columns (out / cross-q / cross-out, ffn2), which a wider tile
 //          cannot spread over the chip
 //   cfg 2: 2 x 2 waves, 128 x 128, 1 k-step per stage, 4 stages (64 KB)
-//   cfg 6: cfg 1's tile with TWO k-steps per stage, ring of 4 (96 KB): half the waits and barriers per k-step — ffn2 (K = 5 120:
-//          160 k-steps), 36.5 -> 35.1 us at 1 280 rows
-//   (cfg 3 / 4, the staggered forms of cfg 0, cfg 5 = cfg 6 with a ring of 3 and cfg 7 = cfg 2 with two k-steps per stage were
-//    measured in round 6 and removed: profiles/r06_dec_linear_bench_call2_stagger.txt, _call15_kc2.txt, _call16_cfg7.txt)
+//   (round 6 measured and removed: cfg 3 / 4, cfg 0's tile with two staggered wave groups (10 % slower:
+//    profiles/r06_dec_linear_bench_call2_stagger.txt); cfg 5 / 6, cfg 1's tile with two k-steps per stage and a ring of 3 / 4 — cfg 6
+//    was 4 % FASTER for ffn2 in the isolated table (_call15_kc2.txt) and 18 % SLOWER in the pipeline (96 KB of LDS: one workgroup
+//    per CU and nothing of the other decode lane beside it; profiles/r06_ab_ffn2_cfg.jsonl, two builds alternating on one box:
+//    ffn2 8.8-9.0 vs 10.3-10.9 ms per step) — the isolated table ranks forms of EQUAL LDS footprint only; cfg 7, cfg 2's tile
+//    with two k-steps per stage (_call16_cfg7.txt))
 // (measured next to 256 x 64, 128 x 256, 8 waves on 128 x 128, deeper rings, two k-steps per barrier, LDS reads
 //  software-pipelined under the MFMAs, L2 touch-ahead: profiles/r03_dec_linear_bench.txt — none better)
 template <bool LNF, int S, int WM, int WN, int FB, int KC, int NST>
@@ -1883,7 +1885,6 @@ int launch_dec_gemm_big(hipStream_t st, int cfg, const half_t* xf, const half_t*
     case 0: return big_cfg<4, 2, 4, 2, 3>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 1: return big_cfg<2, 2, 2, 1, 5>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     case 2: return big_cfg<2, 2, 4, 1, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
-    case 6: return big_cfg<2, 2, 2, 2, 4>(st, xf, Wf, bias, s1, cf, res, ldr, out, ldo, out_frag, R, N, K, act);
     default: return -1;
   }
 }
@@ -1921,7 +1922,7 @@ int launch_dec_gemm_frag_variant(hipStream_t st, int variant, bool lnf, const ha
     case 26: frag_variant<8, 1, 2, 6>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 21: frag_variant<4, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
     case 22: frag_variant<8, 4, 4, 5>(st, lnf, xf, Wf, bias, s1, cf, out, R, N, K); break;
-    case 10: case 11: case 12: case 16:
+    case 10: case 11: case 12:
       return launch_dec_gemm_big(st, variant - 10, xf, Wf, lnf ? nullptr : bias, lnf ? s1 : nullptr, lnf ? cf : nullptr,
                                  nullptr, 0, out, N, nullptr, R, N, K, 0);
     default: return -1;
@@ -1944,7 +1945,7 @@ static const DecBigRule DEC_BIG_RULES[4][2] = {
     /* qkv  */ {{640, 2}, {1280, 0}},
     /* dxd  */ {{1088, 1}, {1 << 30, 1}},
     /* ffn1 */ {{512, 2}, {1280, 0}},
-    /* ffn2 */ {{832, 6}, {1 << 30, 6}},   // (two k-steps per stage, ring of 4: 36.5 -> 35.1 us at 1 280 rows, r06_dec_linear_bench_call15_kc2.txt)
+    /* ffn2 */ {{832, 1}, {1 << 30, 1}},   // (NOT the two-k-steps form: 4 % faster isolated, 18 % slower in the pipeline, r06_ab_ffn2_cfg.jsonl)
 };
 static int dec_big_cfg_for(int R, int N, int K) {
   const DecBigRule* r = DEC_BIG_RULES[dec_linear_role(N, K)];

@@ -11,7 +11,7 @@ from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # n
 VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)", 2: "8w 4x2 ch3", 3: "8w 4x2 ch4",
             4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2",
             10: "big 4x2 waves 256x128 KC2x3", 11: "big 2x2 waves 128x64 KC1x5", 12: "big 2x2 waves 128x128 KC1x4",
-            16: "big 2x2 waves 128x64 KC2x4",   # (13 / 14 / 15 / 17: round-6 experiments, removed from the library)
+            # (13 ... 17: round-6 experiments — staggered groups, two k-steps per stage —, removed from the library again)
             21: "4w 4x4 ch5", 22: "8w 4x4 ch5", 23: "4w 1x1 ch10", 24: "8w 1x1 ch10", 25: "4w 1x2 ch6", 26: "8w 1x2 ch6"}
 if os.environ.get("DLB_VARIANTS"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["DLB_VARIANTS"].split(",")}

@@ -73,7 +73,7 @@ int main() {
     run(2, R, 3840, 1280, true);    // 128 x 128, 4 waves (1 k-step per stage, ring of 4)
     run(1, R, 1280, 1280, false);   // d x d, 128 x 64
     run(0, R, 5120, 1280, true);    // ffn1
-    run(6, R, 1280, 5120, false);   // ffn2, 128 x 64 with two k-steps per stage
+    run(1, R, 1280, 5120, false);   // ffn2, 128 x 64
   }
   return 0;
 }

@@ -307,7 +307,7 @@ def test_gemm_cross_kv_fragment_major(model, M, N, K, vt):
     assert err < 2e-3
 
 
-BIG_CFGS = (0, 1, 2, 6)     # workgroup shapes (6: 128 x 64 with two k-steps per stage, round 6) of dec_gemm_big_kernel (dec_kernels.hip: launch_dec_gemm_big)
+BIG_CFGS = (0, 1, 2)     # workgroup shapes of dec_gemm_big_kernel (dec_kernels.hip: launch_dec_gemm_big)
 
 
 @pytest.mark.parametrize("R", [5, 80, 333, 800, 960, 1521, 1680])
