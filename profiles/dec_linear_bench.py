@@ -11,7 +11,7 @@ from faster_whisper_amd import Whisper, _lib, get_config, synthetic_weights  # n
 VARIANTS = {0: "4w 2x2 ch5 (product K<2560)", 1: "8w 2x2 ch5 (product K>=2560)", 2: "8w 4x2 ch3", 3: "8w 4x2 ch4",
             4: "8w 4x4 ch2", 5: "8w 4x4 ch3", 6: "4w 4x2 ch3", 7: "8w 2x4 ch3", 8: "8w 8x2 ch2", 9: "4w 4x4 ch2",
             10: "big 4x2 waves 256x128 KC2x3", 11: "big 2x2 waves 128x64 KC1x5", 12: "big 2x2 waves 128x128 KC1x4",
-            # (13 ... 17: round-6 experiments — staggered groups, two k-steps per stage —, removed from the library again)
+            13: "sp 4 slices x 2x2 waves 128x64 x3",
             21: "4w 4x4 ch5", 22: "8w 4x4 ch5", 23: "4w 1x1 ch10", 24: "8w 1x1 ch10", 25: "4w 1x2 ch6", 26: "8w 1x2 ch6"}
 if os.environ.get("DLB_VARIANTS"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["DLB_VARIANTS"].split(",")}
@@ -33,8 +33,8 @@ def main():
         for v, name in VARIANTS.items():
             t = []
             for _, N, K, lnf in SHAPES:
-                _lib.check(m._lib.fw_bench_dec_linear(h, R, N, K, lnf, v, 400, C.byref(us)))
-                t.append(us.value)
+                rc = m._lib.fw_bench_dec_linear(h, R, N, K, lnf, v, 400, C.byref(us))
+                t.append(us.value if rc == 0 else float("nan"))     # (a form that does not take this shape)
             layer = t[0] + 3 * t[1] + t[2] + t[3]
             flop = 2.0 * R * sum(n * k * (3 if nm == "dxd" else 1) for nm, n, k, _ in SHAPES)
             print("  %-38s" % name + "".join("%10.2f" % x for x in t) + "   %8.1f   %8.0f" % (layer, flop / layer / 1e6), flush=True)
