@@ -272,7 +272,7 @@ def parse_args(argv=None):
                          "weights, shared decode group).  The merged decode run grows with the batches in flight "
                          "and every decoder weight is streamed once per run: measured 6: 2 221x, 8: 2 405x, 12: 2 523x, "
                          "16: 2 595x, 20: 2 740x, 24: 2 765x, 32: 2 834x (decode workspace clamped to 336 chunks by HBM)")
-    ap.add_argument("--decode-lanes", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--decode-lanes", type=int, default=2, choices=[1, 2, 3, 4],
                     help="decode runs in flight per GPU (2: the product's default; 1: one run at a time, used for the kernel "
                          "traces in profiles/ so that kernel durations are not stretched by the other lane's kernels)")
     ap.add_argument("--merge-fill", type=int, default=None,

@@ -654,10 +654,10 @@ static bool idle_balance() {
 // that work needs (at least two: one per lane; more when it exceeds two runs' capacity `want`), never less than one batch
 // (round 6: splitting the known work of an idle group into at least THREE runs instead of two — the first run starting after a
 //  third of a burst's encoder passes — measured +-0.4 % on the 20-batch burst and on the steady state: profiles/r06_ab_idle_runs.jsonl)
-int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch) {
+int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch, int lanes) {
   const int64_t per_req = std::max<int64_t>(1, queued / std::max<int64_t>(1, (int64_t)n_queued));
   const int64_t outstanding = queued + (int64_t)std::max(0, encoding) * per_req;
-  const int64_t n_runs = std::max<int64_t>(2, (outstanding + std::max<int64_t>(1, want) - 1) / std::max<int64_t>(1, want));
+  const int64_t n_runs = std::max<int64_t>(std::max(2, lanes), (outstanding + std::max<int64_t>(1, want) - 1) / std::max<int64_t>(1, want));
   return std::max<int64_t>(max_batch, (outstanding + n_runs - 1) / n_runs);
 }
 static int64_t planned_self_cap(const Model* dm) {   // rows x positions of a lane's self-attention cache
@@ -1012,7 +1012,7 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
   grp.queue.push_back(&req);
   grp.last_arrival = std::chrono::steady_clock::now();
   while (!req.done) {
-    const int n_lanes = dm->lane1 ? 2 : 1;     // (read under grp.mu: stable while a request is queued, see above)
+    const int n_lanes = n_lanes_of(dm);        // (read under grp.mu: stable while a request is queued, see above)
     if (req.taken || grp.gathering || grp.active_runs >= std::min(n_lanes, grp.lanes_enabled.load())) {
       grp.cv.wait(lk);
       continue;
@@ -1046,7 +1046,8 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
         // one request per worker that is inside an encode call (running or waiting for the encoder; counted at the size of
         // the queued requests).  20 batches in flight -> two runs of 10, not one of 18 and leftovers.
         if (idle_balance() && grp.active_runs == 0 && n_lanes >= 2 && grp.lanes_enabled.load() >= 2 &&
-            queued >= idle_lead_chunks(queued, (int)grp.queue.size(), grp.encoding.load(), want, dm->max_batch))
+            queued >= idle_lead_chunks(queued, (int)grp.queue.size(), grp.encoding.load(), want, dm->max_batch,
+                                       std::min(n_lanes, grp.lanes_enabled.load())))
           break;
         if (std::chrono::steady_clock::now() - grp.last_arrival > std::chrono::milliseconds(wait_ms)) break;
         grp.cv.wait_for(lk, std::chrono::microseconds(200));
@@ -1074,7 +1075,8 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
         ++it;
       }
     }
-    const int lane = (n_lanes == 2 && grp.lane_busy[0]) ? 1 : 0;
+    int lane = 0;
+    while (lane + 1 < n_lanes && grp.lane_busy[lane]) ++lane;    // the first free lane (active_runs < lanes: there is one)
     grp.lane_busy[lane] = true;
     grp.active_runs += 1;
     grp.gathering = false;
@@ -1086,7 +1088,7 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     if (chunks > grp.max_run_chunks.load()) grp.max_run_chunks.store(chunks);
     int rc;
     {
-      Model* lm = lane ? dm->lane1 : dm;    // the lane's model: own workspace, own stream, same weights
+      Model* lm = lane_model(dm, lane);     // the lane's model: own workspace, own stream, same weights
       std::lock_guard<std::mutex> dl(lm->dec_mu);
       rc = generate_run(lm, batch);
     }

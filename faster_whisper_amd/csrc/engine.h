@@ -109,8 +109,8 @@ struct DecodeGroup {
   bool gathering = false;         // a caller is collecting the requests of the next run (one at a time)
   bool resizing = false;          // fw_model_set_decode_batch is rebuilding the workspaces / the second lane: callers wait
   int active_runs = 0;            // runs in flight (<= lanes of the group)
-  bool lane_busy[2] = {false, false};
-  std::atomic<int> lanes_enabled{2};   // fw_model_set_decode_lanes: runs allowed in flight (1 or 2)
+  bool lane_busy[4] = {false, false, false, false};
+  std::atomic<int> lanes_enabled{4};   // fw_model_set_decode_lanes: runs allowed in flight (1 .. the lanes the group has)
   std::atomic<int> encoding{0};   // member encodes in flight: requests that are about to arrive
   std::chrono::steady_clock::time_point last_arrival{};   // when the newest request was queued
   std::mutex enc_mu;              // one encoder pass at a time per device
@@ -185,7 +185,9 @@ struct Model {
   // decoder-only model on the same weight blob with a workspace and a stream of its own, so that TWO decode runs of the
   // group are in flight at once — the cross-attention stream of one (HBM-bound) beside the linears of the other:
   // measured +8 % (profiles/r03_two_groups_probe.txt).  Owned by the primary; never visible through the C ABI.
-  Model* lane1 = nullptr;
+  // (FWAMD_DECODE_LANES = 3 / 4 builds further lanes of the same kind — measurement knob, profiles/r06_ab_lanes.jsonl)
+  Model* lane1 = nullptr;        // = xlanes[0]
+  Model* xlanes[3] = {nullptr, nullptr, nullptr};   // lanes 1 .. 3
   bool is_lane = false;
   // The cross-attention K / V^T cache is ONE pool per decode group (owned by the primary, borrowed by the second lane):
   // blocks of max_batch chunk slots, one block per encoder output in flight, handed to whichever lane decodes the
@@ -232,7 +234,7 @@ int dev_alloc(void** p, size_t bytes);
 // frees up.  Measurement knob: FWAMD_DEC_STREAM_PRIO (decode lanes), FWAMD_ENC_STREAM_PRIO (encoder / replica streams).
 hipError_t create_stream(hipStream_t* st, const char* role);   // role "ENC" / "DEC": engine.hip
 // decode groups (decoder.hip): chunks an idle two-lane group waits for before it leads a run
-int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch);
+int64_t idle_lead_chunks(int64_t queued, int n_queued, int encoding, int64_t want, int max_batch, int lanes = 2);
 template <typename T>
 inline int dev_alloc_t(T** p, size_t n) { return dev_alloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
 
@@ -267,6 +269,12 @@ int64_t gen_workspace_bytes(const Model* m, int lane_chunks, int self_ctx);
 int64_t cross_pool_bytes(const Model* m, int pool_chunks);
 void cross_pool_free(Model* m);
 inline Model* decoder_of(Model* m) { return m->decoder ? m->decoder : m; }
+inline int n_lanes_of(const Model* m) {
+  int n = 1;
+  for (const Model* l : m->xlanes) n += l ? 1 : 0;
+  return n;
+}
+inline Model* lane_model(Model* m, int lane) { return lane == 0 ? m : m->xlanes[lane - 1]; }
 inline int lane_chunks_of(const Model* m) {
   const int b = m->lane_batch > 0 ? m->lane_batch : m->decode_batch;
   return b > m->max_batch ? b : m->max_batch;

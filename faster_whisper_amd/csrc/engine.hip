@@ -1157,10 +1157,11 @@ void fw_model_free(fw_model* fm) {
     release[1] = m->decoder;
   }
   (void)hipSetDevice(m->device);
-  if (m->lane1) {
-    fw_model_free(static_cast<fw_model*>(m->lane1->self));
-    m->lane1 = nullptr;
+  for (Model*& l : m->xlanes) {
+    if (l) fw_model_free(static_cast<fw_model*>(l->self));
+    l = nullptr;
   }
+  m->lane1 = nullptr;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   if (m->dec_stream) (void)hipStreamSynchronize(m->dec_stream);
   gen_workspace_free(m);
@@ -1244,8 +1245,10 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   //            positions and a RUN lays it out for its own max_length, so when the budget is short the positions per
   //            row are lowered first (down to 160: a run that asks for more simply holds fewer rows), then the pool.
   int want = std::max(decode_batch, m->max_batch) / m->max_batch * m->max_batch;
-  const int n_lanes = want >= 4 * m->max_batch ? 2 : 1;
-  const int max_rows = n_lanes == 2 ? DEC_GROUP_RUN_ROWS : 2048;
+  int lanes_wanted = 2;
+  if (const char* e = getenv("FWAMD_DECODE_LANES")) lanes_wanted = std::min(4, std::max(1, atoi(e)));
+  const int n_lanes = want >= 4 * m->max_batch ? lanes_wanted : 1;
+  const int max_rows = n_lanes >= 2 ? DEC_GROUP_RUN_ROWS : 2048;
   auto lane_of = [&](int pool_chunks) {
     int lc = pool_chunks;
     while (lc > m->max_batch && (int64_t)lc * m->max_beam > max_rows) lc -= m->max_batch;
@@ -1254,7 +1257,8 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
   size_t free_b = 0, total_b = 0;
   FW_HIP(hipMemGetInfo(&free_b, &total_b));
   if (m->gen) free_b += (size_t)gen_workspace_bytes(m, lane_chunks_of(m), m->decode_self_ctx);
-  if (m->lane1 && m->lane1->gen) free_b += (size_t)gen_workspace_bytes(m->lane1, lane_chunks_of(m->lane1), m->lane1->decode_self_ctx);
+  for (const Model* l : m->xlanes)
+    if (l && l->gen) free_b += (size_t)gen_workspace_bytes(l, lane_chunks_of(l), l->decode_self_ctx);
   if (m->xpool) free_b += (size_t)cross_pool_bytes(m, std::max(m->decode_batch, m->max_batch));
   const int64_t budget = (int64_t)(0.7 * (double)free_b);
   const int NT = m->cfg.n_text_ctx;
@@ -1270,23 +1274,24 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
     want -= m->max_batch;
   }
   const int lane_batch = lane_of(want);
-  const bool lanes_ok = (n_lanes == 2) == (m->lane1 != nullptr);
+  const bool lanes_ok = n_lanes == n_lanes_of(m);
   if (m->gen && m->xpool && lanes_ok && want == m->decode_batch && lane_batch == lane_chunks_of(m) &&
       self_ctx == m->decode_self_ctx)
     return FW_OK;
   if (m->dec_stream) FW_HIP(hipStreamSynchronize(m->dec_stream));
   gen_workspace_free(m);
-  if (m->lane1) {
-    fw_model_free(static_cast<fw_model*>(m->lane1->self));
-    m->lane1 = nullptr;
+  for (Model*& l : m->xlanes) {
+    if (l) fw_model_free(static_cast<fw_model*>(l->self));
+    l = nullptr;
   }
+  m->lane1 = nullptr;
   cross_pool_free(m);
   m->decode_batch = want;
   m->lane_batch = lane_batch;
   m->decode_self_ctx = self_ctx;
   int rc = gen_workspace_ensure(m);     // (creates the pool too)
   if (rc) return rc;
-  if (n_lanes == 2) {
+  for (int k = 1; k < n_lanes; ++k) {
     fw_model* l = nullptr;
     if ((rc = model_from_blob(m->blob, m->blob_bytes, false, m->device, m->max_batch, m->max_beam, &l, true))) return rc;
     l->impl.decode_batch = want;
@@ -1295,15 +1300,23 @@ int32_t fw_model_set_decode_batch(fw_model* fm, int32_t decode_batch) {
     l->impl.pool_owner = m;
     l->impl.prof_on = m->prof_on;
     if ((rc = gen_workspace_ensure(&l->impl))) { fw_model_free(l); return rc; }
-    m->lane1 = &l->impl;
+    m->xlanes[k - 1] = &l->impl;
   }
+  m->lane1 = m->xlanes[0];
   return FW_OK;
 }
 
 int32_t fw_model_set_decode_lanes(fw_model* fm, int32_t lanes) {
   FW_CHECK_ARG(fm, "null model");
-  FW_CHECK_ARG(lanes == 1 || lanes == 2, "decode lanes: 1 or 2");
-  decoder_of(&fm->impl)->grp.lanes_enabled.store(lanes);
+  Model* dm = decoder_of(&fm->impl);
+  int have;
+  {
+    std::lock_guard<std::mutex> gl(dm->grp.mu);     // (the lanes are rebuilt under grp.resizing)
+    have = std::max(2, n_lanes_of(dm));             // (a group that has not built its second lane yet still takes 2 ...
+    if (const char* e = getenv("FWAMD_DECODE_LANES")) have = std::max(have, std::min(4, atoi(e)));   // ... or what it will build)
+  }
+  FW_CHECK_ARG(lanes >= 1 && lanes <= have, "decode lanes: 1 .. %d", have);
+  dm->grp.lanes_enabled.store(lanes);
   return FW_OK;
 }
 
@@ -1590,7 +1603,8 @@ void fw_tensor_free(fw_tensor* t) {
 void fw_prof_enable(fw_model* fm, int32_t on) {
   if (!fm) return;
   fm->impl.prof_on = on != 0;
-  if (fm->impl.lane1) fm->impl.lane1->prof_on = on != 0;
+  for (Model* l : fm->impl.xlanes)
+    if (l) l->prof_on = on != 0;
 }
 void fw_prof_reset(fw_model* fm) {
   if (!fm) return;
@@ -1599,7 +1613,8 @@ void fw_prof_reset(fw_model* fm) {
     std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
     for (auto& p : fm->impl.prof) p = ProfAcc();
   }
-  if (Model* l = fm->impl.lane1) {
+  for (Model* l : fm->impl.xlanes) {
+    if (!l) continue;
     prof_collect(l);
     std::lock_guard<std::mutex> lk(l->prof_mu);
     for (auto& p : l->prof) p = ProfAcc();
@@ -1615,7 +1630,8 @@ int32_t fw_prof_get(fw_model* fm, int32_t i, double* ms, int64_t* launches, doub
     std::lock_guard<std::mutex> lk(fm->impl.prof_mu);
     p = fm->impl.prof[i];
   }
-  if (Model* l = fm->impl.lane1) {   // the second decode lane of the group reports through its primary
+  for (Model* l : fm->impl.xlanes) {   // the further decode lanes of the group report through their primary
+    if (!l) continue;
     prof_collect(l);
     std::lock_guard<std::mutex> lk(l->prof_mu);
     p.ms += l->prof[i].ms; p.launches += l->prof[i].launches; p.flops += l->prof[i].flops; p.bytes += l->prof[i].bytes;
@@ -1631,7 +1647,8 @@ int32_t fw_synchronize(fw_model* fm) {
   FW_HIP(hipSetDevice(fm->impl.device));
   FW_HIP(hipStreamSynchronize(fm->impl.stream));
   if (fm->impl.dec_stream) FW_HIP(hipStreamSynchronize(fm->impl.dec_stream));
-  if (fm->impl.lane1 && fm->impl.lane1->dec_stream) FW_HIP(hipStreamSynchronize(fm->impl.lane1->dec_stream));
+  for (Model* l : fm->impl.xlanes)
+    if (l && l->dec_stream) FW_HIP(hipStreamSynchronize(l->dec_stream));
   return FW_OK;
 }
 int32_t fw_dev_alloc(fw_model* fm, int64_t bytes, void** out_dev) {

@@ -191,7 +191,8 @@ int32_t fw_model_join_decoder(fw_model* worker, fw_model* primary);
  * passes and leftovers (FWAMD_IDLE_BALANCE=0 restores the plain rule). */
 int32_t fw_model_set_merge_wait(fw_model* m, int32_t wait_ms, int32_t fill_percent);
 /* Decode runs the group may have in flight: 2 (default, when the group has two lanes) or 1 (one run at a time: every
- * kernel of a run has the chip to itself — what per-kernel timing wants; takes effect with the next run). */
+ * kernel of a run has the chip to itself — what per-kernel timing wants; takes effect with the next run).  A group built
+ * with FWAMD_DECODE_LANES = 3 / 4 in the environment (measurement knob) has that many lanes and takes 1 .. that many. */
 int32_t fw_model_set_decode_lanes(fw_model* m, int32_t lanes);
 /* counters of the decode group `m` belongs to: decode runs, fw_generate calls served, chunks decoded, chunks of
  * the largest run (any pointer may be NULL) */
