@@ -23,6 +23,8 @@ Pinning status
     state machine, chunk merging; `oracle.scripted_backend`, `oracle.micro_tokenizer`,
     `oracle.host_scenarios`): PINNED — `oracle/gen_golden_host.py` runs the reference's own
     transcribe.py / tokenizer.py / vad.py in the build container; fixtures under `tests/golden/`.
-  * Silero VAD network (`oracle.silero`): PARITY UNPINNED (onnxruntime absent); restates the ONNX
-    graph of the reference's asset, plausibility-checked on the reference's speech fixture.
+  * Silero VAD network (`oracle.silero`): PARITY vs onnxruntime UNPINNED (absent); restates the ONNX
+    graph of the reference's asset, plausibility-checked on the reference's speech fixture and pinned
+    to a GENERIC execution of that graph by `oracle.onnx_exec` (every node by its ONNX operator
+    definition on torch's kernels; tests/test_oracle_silero_graph.py: 5.8e-7 with the real weights).
 """

@@ -1,9 +1,13 @@
 """TEST INFRASTRUCTURE — numpy restatement of the Silero VAD v6 network (the ONNX asset the reference runs with
 onnxruntime, faster_whisper/vad.py:288-351) and of `SileroVADModel.__call__`'s window framing.
 
-PARITY UNPINNED: `onnxruntime` is not installed, so no output of the reference's own VAD can be produced here;
-the graph semantics below follow the ONNX operator specification (Pad reflect, Conv, Slice, LSTM with gate order
-i, o, f, c) applied to the node list of `silero_vad_v6.onnx`:
+PARITY vs onnxruntime UNPINNED: `onnxruntime` is not installed, so no output of the reference's own VAD run can be
+produced here.  What the restatement IS pinned to (round 6): the asset's own graph executed generically —
+`oracle/onnx_exec.py` walks the 25 nodes of `silero_vad_v6.onnx` and evaluates each by its ONNX operator definition on
+torch's conv1d / LSTM kernels, knowing nothing of this file — `tests/test_oracle_silero_graph.py`: 5.8e-7 on the
+reference's speech fixture with the real weights, <= 1.6e-6 (probabilities, h, c) with random weights on the committed
+topology.  The graph semantics below follow the ONNX operator specification (Pad reflect, Conv, Slice, LSTM with gate
+order i, o, f, c) applied to the node list of `silero_vad_v6.onnx`:
 
     input [N, 576] (64 context + 512 new samples)
     Pad reflect 128 | 128                     -> [N, 832]
