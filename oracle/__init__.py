@@ -16,7 +16,9 @@ Pinning status
     (transcribe.py:222-236, :1433-1459, :1709-1715, :1823) and on cross-checks against the
     installed `transformers` Whisper implementation: architecture and a whole greedy decode with
     timestamps — tokens, score, no-speech probability — against a loop made of transformers' forward
-    and transformers' own logits processors (tests/test_oracle_arch.py),
+    and transformers' own logits processors, and a whole BEAM-5 decode — all five hypotheses, their order
+    and scores, finishing in different steps — against transformers' own beam search with early stopping
+    (tests/test_oracle_arch.py),
     timestamp / suppress logits rules, median filter and DTW (tests/test_oracle_vs_hf_rules.py:
     identical on random inputs).  Beam-search bookkeeping and int8 conventions stay [CT2-ext].
   * host logic of the callers (prompts, seek loop, temperature fallback, word timestamps, VAD

@@ -12,8 +12,12 @@ restates its published behaviour (OpenNMT/CTranslate2 4.x `src/models/whisper.cc
     detect_language   transcribe.py:215, :1193, :1823-1828
     align             transcribe.py:1709-1746
 The architecture is cross-checked against the installed `transformers` Whisper
-(tests/test_oracle_arch.py).  Every rule that is remembered rather than verified is tagged
-[CT2-ext].
+(tests/test_oracle_arch.py), and so is — round 6 — the BEAM SEARCH bookkeeping: on the same weights
+and rules, `transformers`' own beam search (`GenerationMixin.generate(num_beams=5, early_stopping=True,
+length_penalty=0)`, an independent implementation of the top-2K / first-K-slots / secondary-candidate
+scheme) returns the same five hypotheses in the same order with the same scores, with hypotheses
+finishing before the budget in different steps (test_beam_search_matches_transformers_beam_search).
+Every rule that is remembered rather than verified is tagged [CT2-ext].
 
 Numerics: float32 torch on the CPU.  With `emulate_fp16=True` the tensors the GPU engine
 stores in fp16 (weights, activations between kernels, attention probabilities) are rounded

@@ -144,3 +144,68 @@ def test_greedy_decode_matches_a_loop_built_from_transformers_parts():
             assert g.sequences_ids[0] == toks, (b, g.sequences_ids[0], toks)
             assert abs(g.scores[0] - cum / max(1, len(toks))) < 1e-4 * max(1.0, abs(cum))
             assert abs(g.no_speech_prob - no_speech) < 1e-5
+
+
+@pytest.mark.parametrize("seed,eot_lift", [(21, 0.0), (23, 2.5), (27, 2.5), (28, 2.75), (24, 3.0), (26, 4.0)])
+def test_beam_search_matches_transformers_beam_search(seed, eot_lift):
+    """oracle beam search (the restatement of CTranslate2's BeamSearch::search: top 2K of cum + logp, the first K slots examined,
+    an <eot> candidate among them becomes a finished hypothesis and its slot goes to the next non-<eot> candidate, stop at K
+    finished hypotheses or at the length budget, best first) against transformers' OWN beam search on the same weights —
+    `GenerationMixin.generate(num_beams=5, early_stopping=True)`, an independent implementation of that scheme — with the
+    logits rules in CTranslate2's order (mask, THEN log-softmax: transformers masks after the log-softmax, so a re-normalising
+    processor closes its list).  length_penalty = 0 on both sides: transformers counts the <eot> in a hypothesis' length,
+    CTranslate2 does not (transcribe.py:241-246 inverts exactly that), so only the un-normalised score is comparable.
+    `eot_lift` raises the <eot> logit through the final LayerNorm's bias so that hypotheses finish BEFORE the budget — in
+    different steps, some below rank K (ignored), some replaced by secondary candidates."""
+    from transformers import GenerationConfig
+    from transformers.generation.logits_process import (LogitsProcessor, LogitsProcessorList, SuppressTokensAtBeginLogitsProcessor,
+                                                        SuppressTokensLogitsProcessor)
+    from transformers.generation.utils import GenerationMixin
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=seed, dtype=np.float32)
+    if eot_lift:
+        e = np.asarray(w["dec.tok_emb"][cfg.eot], dtype=np.float32)
+        w["dec.ln.b"] = (np.asarray(w["dec.ln.b"], np.float32) + eot_lift * e / float(e @ e)).astype(np.float32)
+    hf = _load_into_hf(cfg, w)
+    oracle = OracleWhisper(cfg, w, emulate_fp16=False)
+    rng = np.random.default_rng(seed)
+    B, K, n_new = 3, 5, 14
+    feats = rng.standard_normal((B, cfg.n_mels, 3000)).astype(np.float32) * 0.5
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    sup = sorted({cfg.sot, cfg.sot_prev, cfg.sot_lm, cfg.no_speech, cfg.translate, cfg.transcribe, 3, 4, 5})
+
+    class Renormalise(LogitsProcessor):          # CTranslate2: rules on the logits, then log-softmax
+        def __call__(self, input_ids, scores):
+            return torch.log_softmax(scores, dim=-1)
+
+    procs = LogitsProcessorList([SuppressTokensAtBeginLogitsProcessor(list(cfg.suppress_begin), begin_index=len(prompt)),
+                                 SuppressTokensLogitsProcessor(sup), Renormalise()])
+    gc = GenerationConfig(num_beams=K, early_stopping=True, length_penalty=0.0, do_sample=False, num_return_sequences=K,
+                          max_new_tokens=n_new, eos_token_id=cfg.eot, pad_token_id=cfg.eot, bos_token_id=cfg.eot,
+                          decoder_start_token_id=cfg.sot, return_dict_in_generate=True, output_scores=True)
+    enc = oracle.encode(feats)
+    got = oracle.generate(enc, [prompt] * B, beam_size=K, patience=1.0, num_hypotheses=K, length_penalty=0.0,
+                          max_length=len(prompt) + n_new, suppress_tokens=sup, suppress_blank=True)
+    early = 0
+    with torch.no_grad():
+        for b in range(B):
+            out = GenerationMixin.generate(hf, input_features=torch.from_numpy(feats[b:b + 1]),
+                                           decoder_input_ids=torch.tensor([prompt]), generation_config=gc,
+                                           logits_processor=procs)
+            seqs = out.sequences[:, len(prompt):].tolist()
+            hf_hyps = []
+            for s in seqs:
+                s = s[:s.index(cfg.eot)] if cfg.eot in s else s       # (padding after <eot> is <eot>)
+                hf_hyps.append(s)
+            hf_scores = out.sequences_scores.tolist()
+            o_hyps, o_scores = got[b].sequences_ids, got[b].scores
+            early += sum(len(h) < n_new for h in o_hyps)
+            print(f"seed {seed} lift {eot_lift} chunk {b}: lengths oracle {[len(h) for h in o_hyps]} hf {[len(h) for h in hf_hyps]}, "
+                  f"best score {o_scores[0]:.5f} / {hf_scores[0]:.5f}")
+            assert o_hyps[0] == hf_hyps[0], (b, o_hyps[0], hf_hyps[0])
+            assert abs(o_scores[0] - hf_scores[0]) < 2e-3 * max(1.0, abs(hf_scores[0]))
+            # every returned hypothesis, in order (scores are distinct on random weights)
+            assert o_hyps == hf_hyps, (b, o_hyps, hf_hyps)
+            assert np.abs(np.asarray(o_scores) - np.asarray(hf_scores)).max() < 2e-3 * max(1.0, abs(hf_scores[-1]))
+    if eot_lift >= 2.5:
+        assert early > 0, "the lifted <eot> logit did not finish any hypothesis before the budget: the case tests nothing new"
