@@ -209,3 +209,57 @@ def test_beam_search_matches_transformers_beam_search(seed, eot_lift):
             assert np.abs(np.asarray(o_scores) - np.asarray(hf_scores)).max() < 2e-3 * max(1.0, abs(hf_scores[-1]))
     if eot_lift >= 2.5:
         assert early > 0, "the lifted <eot> logit did not finish any hypothesis before the budget: the case tests nothing new"
+
+
+def test_detect_language_and_align_match_a_pipeline_built_from_transformers_parts():
+    """oracle.detect_language and oracle.align against the same quantities assembled from independent parts: transformers'
+    Whisper forward (logits, and the cross-attention probabilities it returns with output_attentions), transformers' ports of
+    openai-whisper's median filter and DTW.  The row selection (<|notimestamps|> .. last text token) and the crop at
+    num_frames // 2 are openai-whisper timing.py's / the reference's (transcribe.py:1709-1746) and are restated here."""
+    gw = pytest.importorskip("transformers.models.whisper.generation_whisper")
+    cfg = get_config("micro")
+    w = synthetic_weights(cfg, seed=31, dtype=np.float32)
+    hf = _load_into_hf(cfg, w)
+    try:
+        hf.config._attn_implementation = "eager"       # (cross-attention probabilities are only returned by the eager path)
+        hf.model.config._attn_implementation = "eager"
+    except Exception:
+        pass
+    oracle = OracleWhisper(cfg, w, emulate_fp16=False)
+    rng = np.random.default_rng(31)
+    B = 2
+    feats = rng.standard_normal((B, cfg.n_mels, 3000)).astype(np.float32) * 0.5
+    enc = oracle.encode(feats)
+    # ---- detect_language: one step on <sot>, softmax over the language ids only
+    got = oracle.detect_language(enc)
+    with torch.no_grad():
+        lg = hf(input_features=torch.from_numpy(feats), decoder_input_ids=torch.full((B, 1), cfg.sot)).logits[:, 0]
+    pr = torch.softmax(lg[:, cfg.lang_begin:cfg.lang_begin + cfg.n_langs].float(), -1).numpy()
+    for b in range(B):
+        ids = [t for t, _ in got[b]]
+        assert ids == [cfg.lang_begin + int(i) for i in np.argsort(-pr[b], kind="stable")]
+        assert np.abs(np.asarray([p for _, p in got[b]]) - np.sort(pr[b])[::-1]).max() < 1e-5
+    # ---- align
+    start = list(cfg.sot_sequence)
+    texts = [[int(t) for t in rng.integers(20, 300, size=9)], [int(t) for t in rng.integers(20, 300, size=5)]]
+    num_frames = [3000, 1830]
+    width = 7
+    res = oracle.align(enc, start, texts, num_frames, median_filter_width=width)
+    heads = oracle.alignment_heads()
+    for b in range(B):
+        toks = start + [cfg.no_timestamps] + texts[b] + [cfg.eot]
+        with torch.no_grad():
+            out = hf(input_features=torch.from_numpy(feats[b:b + 1]), decoder_input_ids=torch.tensor([toks]),
+                     output_attentions=True)
+        assert out.cross_attentions is not None and out.cross_attentions[0] is not None
+        n0 = len(start) + 1
+        tp = torch.softmax(out.logits[0, n0 - 1:n0 - 1 + len(texts[b])].float(), -1)
+        want_probs = [float(tp[i, t]) for i, t in enumerate(texts[b])]
+        assert np.abs(np.asarray(res[b].text_token_probs) - np.asarray(want_probs)).max() < 1e-5
+        nfr = min(cfg.n_audio_ctx, num_frames[b] // 2)
+        wts = torch.stack([out.cross_attentions[l][0, h] for (l, h) in heads])[:, :, :nfr].float()
+        wts = (wts - wts.mean(dim=-2, keepdim=True)) / wts.std(dim=-2, keepdim=True, unbiased=False)
+        wts = gw._median_filter(wts, width)
+        m = wts.mean(dim=0)[n0 - 1:-1]
+        ti, fi = gw._dynamic_time_warping(-m.double().numpy())
+        assert res[b].alignments == list(zip(ti.tolist(), fi.tolist())), b
