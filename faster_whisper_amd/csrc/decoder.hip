@@ -1087,10 +1087,21 @@ int32_t fw_generate(fw_model* fm, const fw_tensor* enc_t, const int32_t* prompts
     grp.n_chunks.fetch_add(chunks);
     if (chunks > grp.max_run_chunks.load()) grp.max_run_chunks.store(chunks);
     int rc;
+    // FWAMD_RUN_LOG=1: one stderr line per decode run (start / end on the host clock, lane, calls, chunks) — the timeline of a
+    // burst (profiles/r06_run_log_burst.txt)
+    static const bool run_log = [] { const char* e = getenv("FWAMD_RUN_LOG"); return e && atoi(e) != 0; }();
+    const auto t_run0 = std::chrono::steady_clock::now();
     {
       Model* lm = lane_model(dm, lane);     // the lane's model: own workspace, own stream, same weights
       std::lock_guard<std::mutex> dl(lm->dec_mu);
       rc = generate_run(lm, batch);
+    }
+    if (run_log) {
+      const auto t_run1 = std::chrono::steady_clock::now();
+      const double s0 = std::chrono::duration<double>(t_run0.time_since_epoch()).count();
+      const double s1 = std::chrono::duration<double>(t_run1.time_since_epoch()).count();
+      fprintf(stderr, "[fwamd run] lane %d calls %d chunks %d start %.4f end %.4f (%.1f ms)\n", lane, (int)batch.size(), chunks,
+              s0, s1, 1e3 * (s1 - s0));
     }
     const std::string err = rc ? fw_last_error() : "";
     lk.lock();
