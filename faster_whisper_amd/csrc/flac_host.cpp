@@ -246,16 +246,20 @@ int read_subframe(Bits& br, int block, int bps, int64_t* out) {
     for (int i = 0; i < order; ++i) out[i] = br.s(bps);
     int rc = read_residual(br, block, order, res.data());
     if (rc) return rc;
+    // (the predictors run in WRAPPING 64-bit arithmetic: a valid stream never leaves its sample range, a corrupted one can
+    //  make the recursion diverge — signed overflow would be undefined behaviour; the frame's CRC-16 rejects such a frame
+    //  afterwards.  Found by tests/native/flac_fuzz.cpp under UBSan.)
+    auto U = [](int64_t v) { return (uint64_t)v; };
     for (int i = order; i < block; ++i) {
-      int64_t p = 0;
+      uint64_t p = 0;
       switch (order) {
-        case 1: p = out[i - 1]; break;
-        case 2: p = 2 * out[i - 1] - out[i - 2]; break;
-        case 3: p = 3 * out[i - 1] - 3 * out[i - 2] + out[i - 3]; break;
-        case 4: p = 4 * out[i - 1] - 6 * out[i - 2] + 4 * out[i - 3] - out[i - 4]; break;
+        case 1: p = U(out[i - 1]); break;
+        case 2: p = 2 * U(out[i - 1]) - U(out[i - 2]); break;
+        case 3: p = 3 * U(out[i - 1]) - 3 * U(out[i - 2]) + U(out[i - 3]); break;
+        case 4: p = 4 * U(out[i - 1]) - 6 * U(out[i - 2]) + 4 * U(out[i - 3]) - U(out[i - 4]); break;
         default: break;
       }
-      out[i] = p + res[i];
+      out[i] = (int64_t)(p + U((int64_t)res[i]));
     }
   } else if (type >= 32) {                           // LPC, order type - 31
     const int order = type - 31;
@@ -271,9 +275,9 @@ int read_subframe(Bits& br, int block, int bps, int64_t* out) {
     int rc = read_residual(br, block, order, res.data());
     if (rc) return rc;
     for (int i = order; i < block; ++i) {
-      int64_t acc = 0;
-      for (int j = 0; j < order; ++j) acc += (int64_t)coef[j] * out[i - 1 - j];
-      out[i] = (acc >> shift) + res[i];
+      uint64_t acc = 0;                              // wrapping, as above
+      for (int j = 0; j < order; ++j) acc += (uint64_t)(int64_t)coef[j] * (uint64_t)out[i - 1 - j];
+      out[i] = (int64_t)((uint64_t)((int64_t)acc >> shift) + (uint64_t)(int64_t)res[i]);
     }
   } else {
     FL_FAIL("FLAC: reserved subframe type %d", type);
