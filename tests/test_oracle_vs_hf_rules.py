@@ -112,3 +112,35 @@ def test_dtw_and_median_filter_match_transformers():
         ti, fi = _dtw(cost.astype(np.float64))
         hti, hfi = gw._dynamic_time_warping(cost.astype(np.float64))
         assert np.array_equal(np.asarray(ti), hti) and np.array_equal(np.asarray(fi), hfi)
+
+
+@pytest.mark.parametrize("penalty,ngram", [(1.3, 0), (1.0, 2), (1.0, 3), (1.15, 3)])
+def test_repetition_penalty_and_ngram_rules_match_transformers(oracle, penalty, ngram):
+    """CTranslate2's RepetitionPenalty / NoRepeatNgram as the oracle restates them (over the GENERATED tokens) against
+    transformers' RepetitionPenaltyLogitsProcessor / NoRepeatNGramLogitsProcessor fed the same token history: the same
+    penalised logits, the same banned tokens.  (Whether CTranslate2 also counts the prompt is [CT2-ext]; the reference's
+    defaults — repetition_penalty 1, no_repeat_ngram_size 0, transcribe.py:752-753 — never reach that question.)"""
+    cfg, o = oracle
+    rng = np.random.default_rng(int(penalty * 100) + ngram)
+    procs = []
+    if penalty != 1.0:
+        procs.append(lp.RepetitionPenaltyLogitsProcessor(penalty))
+    if ngram:
+        procs.append(lp.NoRepeatNGramLogitsProcessor(ngram))
+    banned_any = 0
+    for trial in range(200):
+        n = int(rng.integers(1, 24))
+        hist = [int(x) for x in rng.integers(0, 5, size=n)]        # a small alphabet: repeats and repeated n-grams are common
+        logits = (rng.standard_normal(cfg.n_vocab) * 2).astype(np.float32)
+        ids = torch.tensor([hist], dtype=torch.long)
+        hf = torch.from_numpy(logits.copy())[None]
+        for p in procs:
+            hf = p(ids, hf)
+        hf_lp = torch.log_softmax(hf[0].float(), dim=-1).numpy()
+        mine = o._process_logits(logits, hist, False, None, False, 50, penalty, ngram, 0)
+        assert np.array_equal(np.isneginf(hf_lp), np.isneginf(mine)), (trial, hist)
+        live = ~np.isneginf(mine)
+        assert np.abs(mine[live] - hf_lp[live]).max() < 2e-5
+        banned_any += int(np.isneginf(mine).any())
+    if ngram:
+        assert banned_any > 20          # the n-gram rule fired
