@@ -93,3 +93,27 @@ def test_resampling_removes_out_of_band_energy():
     y = resample(np.sin(2 * np.pi * 10000 * t).astype(np.float32), 48000, 16000)      # above the new Nyquist
     assert np.abs(y[300:-300]).max() < 1e-3
     assert resample(np.zeros(0, np.float32), 48000, 16000).size == 0
+
+
+@pytest.mark.parametrize("rate", [44100, 48000, 8000, 22050, 11025, 32000])
+def test_polyphase_evaluation_equals_scipy_resample_poly(rate):
+    """the resampler's polyphase indexing — phase alignment, output length ceil(n * up / down), zero-padded edges — against an
+    independent implementation fed the SAME filter: scipy.signal.resample_poly(x, up, down, window=h / up) (scipy scales the
+    taps it is given by `up`).  This pins the evaluation, not the filter design: libswresample's own filter
+    (faster_whisper/audio.py:37-41 resamples through PyAV) stays unpinned without FFmpeg."""
+    sig = pytest.importorskip("scipy.signal")
+    from math import gcd
+    rng = np.random.default_rng(rate)
+    x = (rng.standard_normal(rate // 2 + 17) * 0.3).astype(np.float32)
+    y = resample(x, rate, 16000)
+    g = gcd(rate, 16000)
+    up, down = 16000 // g, rate // g
+    big, tpp, beta = max(up, down), 32, 9.0                       # resample()'s defaults
+    half = tpp * big // 2
+    t = np.arange(-half, half + 1, dtype=np.float64)
+    cutoff = 0.5 / big
+    h = 2 * cutoff * np.sinc(2 * cutoff * t) * np.kaiser(t.size, beta)
+    h *= up / h.sum()
+    z = sig.resample_poly(x.astype(np.float64), up, down, window=h / up)
+    assert len(y) == len(z) == -(-len(x) * up // down)
+    assert np.abs(y - z).max() < 1e-6
