@@ -224,6 +224,34 @@ def test_decode_lanes_switch():
                 assert a.sequences_ids == b.sequences_ids and a.scores == b.scores, (lanes, i)
 
 
+def test_four_decode_lanes_knob(monkeypatch):
+    """FWAMD_DECODE_LANES=4 (measurement knob, profiles/ab_r06_lanes.py): the group builds four lanes, fw_model_set_decode_lanes
+    takes 1 .. 4 (5 refused), eight concurrent callers get what each gets alone whatever the number of runs in flight"""
+    monkeypatch.setenv("FWAMD_DECODE_LANES", "4")
+    cfg, model = _model("micro", 8)                   # 24 chunks >= 4 encoder batches: the lanes are built
+    lib = model._lib
+    assert lib.fw_model_set_decode_lanes(model._replicas[0].handle, 5) != 0
+    prompt = list(cfg.sot_sequence) + [cfg.no_timestamps]
+    kw = dict(beam_size=5, max_length=len(prompt) + 8, return_scores=True)
+    batches = _batches(8, 3)
+    ref = [model.generate(model.encode_pcm(b), [prompt] * 3, **kw) for b in batches]
+    for lanes in (4, 3, 1, 4):
+        model.set_decode_lanes(lanes)
+        out = [None] * 8
+
+        def work(i):
+            out[i] = model.generate(model.encode_pcm(batches[i]), [prompt] * 3, **kw)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i in range(8):
+            for a, b in zip(out[i], ref[i]):
+                assert a.sequences_ids == b.sequences_ids and a.scores == b.scores, (lanes, i)
+
+
 def test_decode_batch_cannot_change_under_a_run():
     """fw_model_set_decode_batch rebuilds the decode workspaces (and the second lane): refused with FW_EINVAL while the
     group has a run in flight, accepted again once it is idle — and results after a resize are what they were"""
